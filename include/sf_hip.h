@@ -1,0 +1,204 @@
+/* sf_hip.h -- C-ABI of the MI355X (gfx950) implementation of Self-Forcing's chunk-wise
+ * autoregressive denoising hot path.
+ *
+ * The reference (alazarteka/Self-Forcing) is pure Python/PyTorch and has no FFI layer of
+ * its own: the path sits behind `WanDiffusionWrapper.forward` (utils/wan_wrapper.py:253-349)
+ * and `CausalWanModel._forward_inference` (wan/modules/causal_model.py:725-893), whose heavy
+ * ops go to third-party kernels (flash_attn, cuBLAS, cuDNN).  Each entry point below replaces
+ * one of those op sequences; the citation on each says which.  `INTEGRATION.md` shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - every tensor is bf16 (uint16 storage) unless stated; row-major; strides in ELEMENTS;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), allocates nothing, never synchronises, keeps no global state;
+ *   - return 0 on success, negative on error; `sf_last_error()` gives a thread-local message.
+ */
+#ifndef SF_HIP_H
+#define SF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_HIP_ABI_VERSION 1
+
+int sf_abi_version(void);
+const char* sf_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue: out[M,N] = epi(a[M,K] @ w[N,K]^T + bias[N]).
+ * Replaces nn.Linear (cuBLAS) + the elementwise ops that follow it in
+ * wan/modules/causal_model.py:112-114 (q/k/v), :240 (o), :277-279 (ffn), :320/:331 (gated
+ * residual), model.py:172-193 (cross-attention projections), causal_model.py:366 (head).
+ * fp32 accumulation on the matrix cores; one rounding to bf16 at the store. */
+enum sf_epilogue {
+  SF_EPI_BIAS = 0,            /* y                                             */
+  SF_EPI_BIAS_GELU = 1,       /* gelu_tanh(y)                                  */
+  SF_EPI_BIAS_RESID = 2,      /* resid + y                                     */
+  SF_EPI_BIAS_GATE_RESID = 3  /* resid + y * (gate_mod[n] + gate_e0[group(m)][n]) */
+};
+
+typedef struct sf_gemm_args {
+  const void* a;       /* [M, K], row stride lda                       */
+  const void* w;       /* [N, K], row stride ldw (nn.Linear.weight)    */
+  const void* bias;    /* [N] or NULL                                  */
+  void* out;           /* [M, N], row stride ldo                       */
+  const void* resid;   /* [M, N], row stride ldr; may alias out        */
+  const void* gate_mod; /* [N]   (block.modulation[:, 2 or 5])         */
+  const void* gate_e0;  /* [groups, *] first element of the gate chunk */
+  int64_t gate_group_stride; /* elements between consecutive groups in gate_e0 */
+  int32_t rows_per_group;    /* group(m) = m / rows_per_group                   */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldo, ldr;
+  int32_t epilogue;    /* enum sf_epilogue */
+} sf_gemm_args;
+
+int sf_gemm_bf16(const sf_gemm_args* args, void* stream);
+
+/* Small-M linear layer (M <= 32), weight-bandwidth bound: out = act_out(act_in(x) @ w^T + b).
+ * Replaces the time-embedding MLPs, causal_model.py:464-467, :829-832.
+ * act codes: 0 none, 1 SiLU, 2 GELU-tanh. */
+int sf_small_linear(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
+                    int act_in, int act_out, void* stream);
+
+/* Sinusoidal timestep embedding in float64, wan/modules/model.py:15-25.
+ * t: [n] float32 (t_is_int64 = 0) or int64 (= 1); out [n, dim] bf16 = cat(cos, sin). */
+int sf_sinusoid_embedding(const void* t, int t_is_int64, void* out, int n, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (no affine, eps) + AdaLN modulate: out = LN(x) * (1 + scale) + shift with
+ * scale = mod_scale[c] + e0_scale[group(row)][c], shift likewise; group(row) = row / rows_per_group.
+ * Replaces norm1/norm2/head.norm + the broadcast mul/add of causal_model.py:315, :327-328, :366. */
+int sf_layernorm_modulate(const void* x, void* out, int M, int C, float eps, const void* mod_shift,
+                          const void* mod_scale, const void* e0_shift, const void* e0_scale,
+                          int64_t e0_group_stride, int rows_per_group, void* stream);
+
+/* LayerNorm with affine weight/bias (norm3, causal_model.py:268-270, :324). */
+int sf_layernorm_affine(const void* x, const void* weight, const void* bias, void* out, int M, int C,
+                        float eps, void* stream);
+
+/* WanRMSNorm over the full channel dim (model.py:70-86): out = bf16(x * rsqrt(mean(x^2)+eps)) * w.
+ * x has row stride ldx, out row stride ldo (in place allowed). */
+int sf_rmsnorm(const void* x, int ldx, const void* weight, void* out, int ldo, int M, int C, float eps,
+               void* stream);
+
+/* Fused q/k RMSNorm + 3-axis RoPE + KV-cache write for the fused qkv projection output
+ * (causal_model.py:112-114, :195-200, :221-229).
+ *   qkv   [B*L, 3C]  (q | k | v per row), L = f*h*w tokens per sample in (f,h,w) order
+ *   q_out [B*L, C]   roped, normalised queries
+ *   k_cache/v_cache [B, cache_tokens, H, D]: rows [write_start, write_start+L) are overwritten
+ *   rope_cos/sin: float32 [1024, D/2] tables in the reference's `freqs` column layout
+ *   (time | height | width), time index offset by start_frame. */
+int sf_qkv_norm_rope_cache(const void* qkv, const void* norm_q_w, const void* norm_k_w, void* q_out,
+                           void* k_cache, void* v_cache, const float* rope_cos, const float* rope_sin,
+                           int B, int f, int h, int w, int C, int num_heads, int64_t cache_tokens,
+                           int write_start, int start_frame, float eps, void* stream);
+
+/* Rolling-window eviction, causal_model.py:212-217: for every sample move
+ * cache[sink+evict : sink+evict+keep] -> cache[sink : sink+keep] (overlap-safe). */
+int sf_kv_evict(void* cache, int B, int64_t cache_tokens, int row_elems, int sink, int evict, int keep,
+                void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Non-causal attention softmax(q k^T / sqrt(D)) v, D = 128.  Replaces flash_attn_varlen_func /
+ * SDPA of wan/modules/attention.py:136-150, :198 for self-attention over the KV cache
+ * (causal_model.py:230-234) and for T5 cross-attention (model.py:189).
+ *   q   [B, Lq, H, D]  with token stride q_stride (elements) and batch stride q_bstride
+ *   k,v [B, Lk, H, D]  with token stride kv_stride and batch stride kv_bstride
+ *   out [B, Lq, H, D]  token stride o_stride, batch stride o_bstride */
+int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                 int64_t q_stride, int64_t q_bstride, int64_t kv_stride, int64_t kv_bstride,
+                 int64_t o_stride, int64_t o_bstride, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Patch gather for the (1,2,2) Conv3d patch embedding, causal_model.py:458-459, :775-781:
+ * x [B, F, Cin, H, W] (the wrapper's layout) -> cols [B*F*(H/2)*(W/2), Cin*4] with column index
+ * c*4 + p*2 + q, so that cols @ patch_embedding.weight.flatten(1)^T is the convolution. */
+int sf_patchify(const void* x, void* cols, int B, int F, int Cin, int H, int W, void* stream);
+
+/* Unpatchify (causal_model.py:1081-1104) fused with flow -> x0 (wan_wrapper.py:204-228):
+ *   head_out [B*F*h*w, 4*Cout] (column = (p*2+q)*Cout + c) -> flow [B, F, Cout, H, W],
+ *   x0 = xt - sigma(t) * flow evaluated in float64; sigma by nearest-timestep lookup in the
+ *   n_table-entry float32 tables.  timestep has B*groups entries (frames_per_group = F/groups). */
+int sf_unpatchify_x0(const void* head_out, const void* xt, const void* timestep, int t_is_int64,
+                     const float* sigmas, const float* timesteps, int n_table, void* flow, void* x0,
+                     int B, int F, int groups, int Cout, int H, int W, void* stream);
+
+/* FlowMatchScheduler.add_noise (utils/scheduler.py:159-176): out = (1-sigma) x0 + sigma eps in
+ * fp32; one timestep per leading index (n_outer), inner = C*H*W elements each. */
+int sf_add_noise(const void* x0, const void* eps, const void* timestep, int t_is_int64,
+                 const float* sigmas, const float* timesteps, int n_table, void* out, int n_outer,
+                 int64_t inner, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One whole denoiser pass: CausalWanModel._forward_inference + flow->x0
+ * (causal_model.py:725-893, wan_wrapper.py:288-300, :340-344) as a single host call that
+ * enqueues every kernel on `stream`. */
+typedef struct sf_layer_weights {
+  const void* modulation;                 /* [6, C] */
+  const void *norm3_w, *norm3_b;          /* [C]    */
+  const void *qkv_w, *qkv_b;              /* [3C, C], [3C]: self_attn q|k|v stacked */
+  const void *norm_q_w, *norm_k_w;        /* [C]    */
+  const void *o_w, *o_b;                  /* [C, C] */
+  const void *cq_w, *cq_b;                /* cross_attn.q */
+  const void *ckv_w, *ckv_b;              /* [2C, C]: cross_attn k|v stacked */
+  const void *cnorm_q_w, *cnorm_k_w;
+  const void *co_w, *co_b;
+  const void *ffn0_w, *ffn0_b;            /* [ffn, C] */
+  const void *ffn2_w, *ffn2_b;            /* [C, ffn] */
+} sf_layer_weights;
+
+typedef struct sf_model {
+  int32_t dim, ffn_dim, num_heads, num_layers, in_dim, out_dim, freq_dim, text_dim, text_len;
+  float eps;
+  const void *patch_w, *patch_b;          /* [C, in_dim*4] */
+  const void *text0_w, *text0_b, *text2_w, *text2_b;
+  const void *time0_w, *time0_b, *time2_w, *time2_b;
+  const void *tproj_w, *tproj_b;          /* [6C, C] */
+  const void *head_w, *head_b;            /* [4*out_dim, C] */
+  const void* head_mod;                   /* [2, C] */
+  const sf_layer_weights* layers_host;    /* HOST array [num_layers] */
+  const float *rope_cos, *rope_sin;       /* float32 [1024, 64] */
+  const float *sched_sigmas, *sched_timesteps; /* float32 [n_table] */
+  int32_t n_table;
+} sf_model;
+
+typedef struct sf_forward_args {
+  int32_t batch, frames, lat_h, lat_w;    /* noisy: [B, F, in_dim, H, W] */
+  int32_t groups;                         /* timestep.shape[1] (modulation groups)       */
+  const void* noisy;
+  const void* timestep;                   /* [B, groups] */
+  int32_t t_is_int64;
+  const void* prompt_embeds;              /* [B, text_len, text_dim], zero padded; read only if init_cross */
+  int32_t init_cross;                     /* 1: (re)compute text embedding + cross-attn K/V caches */
+  void* const* k_cache_host;              /* HOST arrays [num_layers] of device pointers */
+  void* const* v_cache_host;              /*   each [B, cache_tokens, H, D]              */
+  void* const* ck_cache_host;             /*   each [B, text_len, H, D]                  */
+  void* const* cv_cache_host;
+  int64_t cache_tokens;
+  /* cache plan (host integers; see kv_cache_plan in self-forcing_amd/kvcache.py) */
+  int32_t sink_tokens, evict, keep;       /* evict > 0: roll the window first */
+  int32_t write_start;                    /* rows [write_start, write_start + F*h*w) get the new K/V */
+  int32_t attn_start, attn_end;           /* attend over cache rows [attn_start, attn_end) */
+  int32_t start_frame;                    /* RoPE time offset = current_start // (h*w) */
+  void* evict_scratch;                    /* >= batch * keep * dim * 2 bytes when evict > 0 */
+  size_t evict_scratch_bytes;
+  void* flow_out;                         /* [B, F, out_dim, H, W] */
+  void* x0_out;                           /* [B, F, out_dim, H, W] */
+  void* workspace;
+  size_t workspace_bytes;
+} sf_forward_args;
+
+size_t sf_dit_workspace_bytes(const sf_model* model, int batch, int frames, int lat_h, int lat_w,
+                              int groups);
+int sf_dit_forward(const sf_model* model, const sf_forward_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF_HIP_H */

@@ -3,9 +3,19 @@ rollout (the `WanDiffusionWrapper` / `CausalInferencePipeline` hot path).
 
 Host code is Python; all device work is hand-written HIP for gfx950 behind the C-ABI
 declared in `include/sf_hip.h` (built into `self-forcing_amd/csrc/libsf_hip.so`).
-There is no CPU or eager-PyTorch fallback: importing the compute entry points without
-the built library raises.
+There is no CPU or eager-PyTorch fallback: the compute entry points raise when the
+library has not been built.
 """
-from .weights import WanShape, WAN_1_3B, WAN_14B, WAN_REDUCED, NAMED_SHAPES, synth_state_dict  # noqa: F401
+from .weights import (WanShape, WAN_1_3B, WAN_14B, WAN_REDUCED, NAMED_SHAPES, synth_state_dict,  # noqa: F401
+                      param_shapes, merge_lora, strip_prefix)
+from .kvcache import CachePlan, plan_cache_update  # noqa: F401
+from .scheduler import FlowMatchScheduler  # noqa: F401
+from .wan_wrapper import WanDiffusionWrapper  # noqa: F401
+from .pipeline import CausalInferencePipeline  # noqa: F401
+from .harness import SyntheticTextEncoder, FixedTextEncoder, IdentityVAE  # noqa: F401
+from . import ops, _lib  # noqa: F401
 
-__all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict"]
+__all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict",
+           "param_shapes", "merge_lora", "strip_prefix", "CachePlan", "plan_cache_update",
+           "FlowMatchScheduler", "WanDiffusionWrapper", "CausalInferencePipeline",
+           "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "ops"]

@@ -1,0 +1,262 @@
+// Non-causal flash attention forward for gfx950 (MI355X), head_dim = 128, bf16 in/out.
+//
+// Replaces flash_attn_varlen_func / SDPA on the reference's hot path
+// (wan/modules/attention.py:136-150, :198) for self-attention over the growing KV cache
+// (wan/modules/causal_model.py:230-234; Lk = 1560 ... 32760) and T5 cross-attention
+// (wan/modules/model.py:189; Lk = 512).  No mask: causality comes only from what is in the cache.
+//
+// Structure (v1).  One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns
+// 32 query rows and walks the keys in tiles of 64.  Per tile and wave:
+//   S^T[key][q]  = K_tile . Q^T        16 x v_mfma_f32_32x32x16_bf16   (A = K rows from LDS,
+//                                                                       B = Q fragments in VGPRs)
+//   online softmax on S^T: the query index is the LANE (col = lane & 31), so the running max /
+//   sum of a query row live in one lane pair (l, l+32) -- one cross-half shuffle per tile, no LDS;
+//   O^T[d][q]   += V_tile^T . P^T      16 x v_mfma_f32_32x32x16_bf16   (A = V^T via
+//                   ds_read_b64_tr_b16 transposing reads, B = the S^T accumulator registers
+//                   converted to bf16 in place: an accumulator tile is directly the next MFMA's
+//                   B operand when the product sums over its row index).
+// K and V tiles are register-staged HBM -> VGPR -> LDS (loads for tile t+1 are issued before the
+// MFMAs of tile t and written to the other LDS buffer afterwards; one barrier per tile).
+// LDS image of a [64 keys][128 d] bf16 tile: 256-byte rows, the 16-byte chunk `ch` of row `row`
+// lives at chunk ch ^ (((row&3)<<2) | ((row>>2)&3)); this one image serves the row reads
+// (ds_read_b128, K) and the transposed reads (V) without bank conflicts.
+#include "sf_common.h"
+#include "../../include/sf_hip.h"
+
+namespace {
+
+constexpr int HD = 128;          // head dim
+constexpr int QT = 128;          // query rows per workgroup
+constexpr int KT = 64;           // keys per tile
+constexpr int ATT_THREADS = 256;
+constexpr int TILE_B = KT * HD * 2;          // 16 KiB
+constexpr int ATT_LDS = 2 * 2 * TILE_B;      // {K,V} x 2 buffers = 64 KiB
+
+struct AttP {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  bf16_t* o;
+  int B, H, Lq, Lk;
+  long q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride;
+  int q_tiles;
+  float scale_log2;  // (1/sqrt(D)) * log2(e)
+};
+
+__device__ __forceinline__ int lds_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ bf16x4 lds_tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+}
+
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware bijective remap so that workgroups on one XCD share (batch, head) -> K/V hit in L2.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = wg / p.q_tiles, qt = wg - bh * p.q_tiles;
+  const int b = bh / p.H, head = bh - b * p.H;
+
+  const bf16_t* qbase = p.q + (long)b * p.q_bstride + head * HD;
+  const bf16_t* kbase = p.k + (long)b * p.kv_bstride + head * HD;
+  const bf16_t* vbase = p.v + (long)b * p.kv_bstride + head * HD;
+  bf16_t* obase = p.o + (long)b * p.o_bstride + head * HD;
+
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int qrow = qt * QT + wave * 32 + r32;
+  const int qrow_c = min(qrow, p.Lq - 1);
+
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane holds Q[q][16 s + 8 hh + j]
+  bf16x8 qf[8];
+  {
+    const bf16_t* qp = qbase + (long)qrow_c * p.q_stride + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  // ---- staging geometry: thread t moves chunks idx = t + 256 i, i = 0..3 of each 16 KiB tile
+  const int st_row = tid >> 4;        // + 16 i
+  const int st_ch = tid & 15;
+  int st_lds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st_lds[i] = lds_off(st_row + 16 * i, st_ch);
+
+  u32x4 kreg[4], vreg[4];
+  auto load_tile = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = min(key0 + st_row + 16 * i, p.Lk - 1);
+      const long off = (long)key * p.kv_stride + st_ch * 8;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + off);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + off);
+    }
+  };
+  auto write_tile = [&](int buf) {
+    char* kb = smem + buf * (2 * TILE_B);
+    char* vb = kb + TILE_B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(kb + st_lds[i]) = kreg[i];
+      *reinterpret_cast<u32x4*>(vb + st_lds[i]) = vreg[i];
+    }
+  };
+
+  // ---- fragment read offsets
+  // K rows: lane reads row (kb*32 + r32), chunk 2 s + hh
+  int k_off[2][8];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) k_off[kb][s] = lds_off(kb * 32 + r32, 2 * s + hh);
+  // V transposed reads: 16-lane group g: d base = db*32 + 16 (g&1); key rows r0 = 16 ks + 4 hh (+8)
+  const int g = lane >> 4, i16 = lane & 15;
+  const int tq = i16 >> 2, tp = i16 & 3;
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2;
+
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);
+    const char* kb_lds = smem + cur * (2 * TILE_B);
+    const char* vb_lds = kb_lds + TILE_B;
+
+    // ---- S^T = K . Q^T
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_lds + k_off[kb][s]);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+      }
+    }
+
+    // ---- mask the tail keys of the last tile
+    if (t == ntiles - 1 && (p.Lk & (KT - 1)) != 0) {
+      const int key0 = t * KT + 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= p.Lk) st[kb][r] = -1e30f;
+        }
+    }
+
+    // ---- online softmax (per query = per lane pair)
+    float mx = st[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(st[kb][r] * c - mc);
+        st[kb][r] = pv;
+        lsum += pv;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+
+    // ---- P^T fragments (B operand): k-step ks <- registers 8 (ks&1) .. +7 of st[ks>>1]
+    bf16x8 pf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16_t)st[ks >> 1][8 * (ks & 1) + j];
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int r0 = 16 * ks + 4 * hh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int c0 = 4 * db + 2 * (g & 1);
+        const bf16x4 lo = lds_tr_read(vb_lds + lds_off(r0 + tq, c0 + (tp >> 1)) + 8 * (tp & 1));
+        const bf16x4 hi = lds_tr_read(vb_lds + lds_off(r0 + 8 + tq, c0 + (tp >> 1)) + 8 * (tp & 1));
+        bf16x8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o_acc[db], 0, 0, 0);
+      }
+    }
+
+    if (t + 1 < ntiles) write_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < p.Lq) {
+    bf16_t* op = obase + (long)qrow * p.o_stride + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(o_acc[db][4 * rg + j] * inv);
+        *reinterpret_cast<bf16x4*>(op + db * 32 + rg * 8) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
+                            int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
+                            int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, void* stream) {
+  SF_CHECK(q && k && v && out, "sf_attention: null tensor");
+  SF_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sf_attention: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
+  SF_CHECK(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0, "sf_attention: strides must keep 16-byte row alignment");
+  SF_CHECK(q_bstride % 8 == 0 && kv_bstride % 8 == 0 && o_bstride % 4 == 0, "sf_attention: batch strides must keep alignment");
+  SF_CHECK(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),
+           "sf_attention: misaligned tensor");
+  AttP p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)out;
+  p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
+  p.q_stride = q_stride; p.q_bstride = q_bstride; p.kv_stride = kv_stride; p.kv_bstride = kv_bstride;
+  p.o_stride = o_stride; p.o_bstride = o_bstride;
+  p.q_tiles = (Lq + QT - 1) / QT;
+  p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
+  const long nwg = (long)p.q_tiles * H * B;
+  SF_CHECK(nwg < (1L << 30), "sf_attention: grid too large");
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)nwg), dim3(ATT_THREADS), ATT_LDS, (hipStream_t)stream, p);
+  SF_HIP_LAUNCH_CHECK("sf_attention");
+  return 0;
+}

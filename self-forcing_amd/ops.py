@@ -1,0 +1,207 @@
+"""Per-kernel Python entry points over the C-ABI (torch tensors in, torch tensors out).
+
+torch is used only for device memory and the current stream; every computation below runs in
+the hand-written HIP kernels of csrc/.  All functions require CUDA(ROCm) bf16 tensors and
+raise if the library is missing -- there is no fallback path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU,
+                   EPI_BIAS_RESID, GemmArgs, check, lib)
+
+Tensor = torch.Tensor
+_EPI = {"bias": EPI_BIAS, "gelu": EPI_BIAS_GELU, "resid": EPI_BIAS_RESID, "gate_resid": EPI_BIAS_GATE_RESID}
+_ACT = {None: ACT_NONE, "none": ACT_NONE, "silu": ACT_SILU, "gelu": ACT_GELU}
+
+
+def stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/ROCm tensor (the HIP path has no CPU fallback)")
+    if t.dtype != torch.bfloat16:
+        raise ValueError(f"{name}: expected bfloat16, got {t.dtype}")
+    return t
+
+
+def _rows(t: Tensor, name: str) -> Tensor:
+    """2-D view with unit inner stride."""
+    _bf16(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _timestep(t: Tensor):
+    if t.dtype == torch.int64:
+        return t.contiguous(), 1
+    return t.to(torch.float32).contiguous(), 0
+
+
+# --------------------------------------------------------------------------------------
+def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: str = "bias",
+         resid: Optional[Tensor] = None, gate_mod: Optional[Tensor] = None, gate_e0: Optional[Tensor] = None,
+         rows_per_group: int = 1, out: Optional[Tensor] = None) -> Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  gate_e0: [groups, N] view (row stride free)."""
+    a, w = _rows(a, "a"), _rows(w, "w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    _rows(out, "out")
+    g = GemmArgs()
+    g.a, g.w, g.bias, g.out = a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldw, g.ldo = a.stride(0), w.stride(0), out.stride(0)
+    g.epilogue = _EPI[epilogue]
+    g.rows_per_group = rows_per_group
+    if resid is not None:
+        _rows(resid, "resid")
+        g.resid, g.ldr = resid.data_ptr(), resid.stride(0)
+    if gate_mod is not None:
+        g.gate_mod = _bf16(gate_mod, "gate_mod").data_ptr()
+    if gate_e0 is not None:
+        _rows(gate_e0, "gate_e0")
+        g.gate_e0, g.gate_group_stride = gate_e0.data_ptr(), gate_e0.stride(0)
+    check(lib().sf_gemm_bf16(g, stream_handle()), "sf_gemm_bf16")
+    return out
+
+
+def small_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], act_in=None, act_out=None) -> Tensor:
+    x, w = _rows(x, "x").contiguous(), _rows(w, "w").contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    check(lib().sf_small_linear(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), M, N, K,
+                                _ACT[act_in], _ACT[act_out], stream_handle()), "sf_small_linear")
+    return out
+
+
+def sinusoid_embedding(t: Tensor, dim: int) -> Tensor:
+    tt, is64 = _timestep(t.flatten())
+    out = torch.empty(tt.numel(), dim, dtype=torch.bfloat16, device=t.device)
+    check(lib().sf_sinusoid_embedding(tt.data_ptr(), is64, out.data_ptr(), tt.numel(), dim, stream_handle()),
+          "sf_sinusoid_embedding")
+    return out
+
+
+def layernorm_modulate(x: Tensor, mod_shift: Tensor, mod_scale: Tensor, e0_shift: Tensor, e0_scale: Tensor,
+                       rows_per_group: int, eps: float = 1e-6) -> Tensor:
+    """x [M,C]; mod_* [C]; e0_* [groups, C] views sharing one row stride."""
+    x = _rows(x, "x").contiguous()
+    M, Cc = x.shape
+    _rows(e0_shift, "e0_shift"), _rows(e0_scale, "e0_scale")
+    if e0_shift.stride(0) != e0_scale.stride(0):
+        raise ValueError("layernorm_modulate: e0_shift / e0_scale must share a row stride")
+    out = torch.empty_like(x)
+    check(lib().sf_layernorm_modulate(x.data_ptr(), out.data_ptr(), M, Cc, eps, mod_shift.data_ptr(), mod_scale.data_ptr(),
+                                      e0_shift.data_ptr(), e0_scale.data_ptr(), e0_shift.stride(0), rows_per_group,
+                                      stream_handle()), "sf_layernorm_modulate")
+    return out
+
+
+def layernorm_affine(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-6) -> Tensor:
+    x = _rows(x, "x").contiguous()
+    out = torch.empty_like(x)
+    check(lib().sf_layernorm_affine(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                    eps, stream_handle()), "sf_layernorm_affine")
+    return out
+
+
+def rmsnorm(x: Tensor, weight: Tensor, eps: float = 1e-6, out: Optional[Tensor] = None) -> Tensor:
+    x = _rows(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib().sf_rmsnorm(x.data_ptr(), x.stride(0), weight.data_ptr(), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                           eps, stream_handle()), "sf_rmsnorm")
+    return out
+
+
+def qkv_norm_rope_cache(qkv: Tensor, norm_q_w: Tensor, norm_k_w: Tensor, k_cache: Tensor, v_cache: Tensor,
+                        rope_cos: Tensor, rope_sin: Tensor, grid, write_start: int, start_frame: int,
+                        eps: float = 1e-6) -> Tensor:
+    """qkv [B*L, 3C]; caches [B, S, H, D]; returns roped q [B*L, C]; writes K/V rows in place."""
+    qkv = _rows(qkv, "qkv").contiguous()
+    B, S, H, D = k_cache.shape
+    f, h, w = grid
+    Cc = H * D
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()):
+        raise ValueError("qkv_norm_rope_cache: caches must be contiguous [B, S, H, D]")
+    q = torch.empty(qkv.shape[0], Cc, dtype=torch.bfloat16, device=qkv.device)
+    check(lib().sf_qkv_norm_rope_cache(qkv.data_ptr(), norm_q_w.data_ptr(), norm_k_w.data_ptr(), q.data_ptr(), k_cache.data_ptr(),
+                                       v_cache.data_ptr(), rope_cos.data_ptr(), rope_sin.data_ptr(), B, f, h, w, Cc, H, S,
+                                       write_start, start_frame, eps, stream_handle()), "sf_qkv_norm_rope_cache")
+    return q
+
+
+def kv_evict(cache: Tensor, sink: int, evict: int, keep: int, scratch: Tensor) -> None:
+    B, S, H, D = cache.shape
+    check(lib().sf_kv_evict(cache.data_ptr(), B, S, H * D, sink, evict, keep, scratch.data_ptr(),
+                            scratch.numel() * scratch.element_size(), stream_handle()), "sf_kv_evict")
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    """q [B,Lq,H,128], k/v [B,Lk,H,128] (token/batch strides free, [H,D] contiguous) -> [B,Lq,H,128]."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _bf16(t, n)
+        if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1 or t.stride(2) != 128:
+            raise ValueError(f"attention: {n} must be [B, L, H, 128] with contiguous heads, got {tuple(t.shape)} {t.stride()}")
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    if k.stride() != v.stride() or k.shape != v.shape:
+        raise ValueError("attention: k and v must share shape and strides")
+    out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    check(lib().sf_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Lq, Lk, q.stride(1), q.stride(0),
+                             k.stride(1), k.stride(0), out.stride(1), out.stride(0), stream_handle()), "sf_attention")
+    return out
+
+
+def patchify(x: Tensor) -> Tensor:
+    """x [B, F, Cin, H, W] -> [B*F*(H/2)*(W/2), Cin*4]."""
+    x = _bf16(x, "x").contiguous()
+    B, F, Cin, H, W = x.shape
+    out = torch.empty(B * F * (H // 2) * (W // 2), Cin * 4, dtype=torch.bfloat16, device=x.device)
+    check(lib().sf_patchify(x.data_ptr(), out.data_ptr(), B, F, Cin, H, W, stream_handle()), "sf_patchify")
+    return out
+
+
+def unpatchify_x0(head_out: Tensor, xt: Tensor, timestep: Tensor, sigmas: Tensor, timesteps: Tensor):
+    """head_out [B*F*h*w, 4*Cout]; xt [B,F,Cout,H,W]; timestep [B, G] -> (flow, x0) [B,F,Cout,H,W]."""
+    xt = _bf16(xt, "xt").contiguous()
+    B, F, Cout, H, W = xt.shape
+    tt, is64 = _timestep(timestep)
+    G = tt.shape[1]
+    flow = torch.empty_like(xt)
+    x0 = torch.empty_like(xt)
+    check(lib().sf_unpatchify_x0(_rows(head_out, "head_out").contiguous().data_ptr(), xt.data_ptr(), tt.data_ptr(), is64,
+                                 sigmas.data_ptr(), timesteps.data_ptr(), sigmas.numel(), flow.data_ptr(), x0.data_ptr(),
+                                 B, F, G, Cout, H, W, stream_handle()), "sf_unpatchify_x0")
+    return flow, x0
+
+
+def add_noise(x0: Tensor, eps: Tensor, timestep: Tensor, sigmas: Tensor, timesteps: Tensor) -> Tensor:
+    """(1 - sigma_t) x0 + sigma_t eps; x0/eps [N, ...], timestep [N]."""
+    x0 = _bf16(x0, "x0").contiguous()
+    eps = _bf16(eps, "eps").contiguous()
+    tt, is64 = _timestep(timestep.flatten())
+    n = x0.shape[0]
+    if tt.numel() != n:
+        raise ValueError(f"add_noise: {n} samples but {tt.numel()} timesteps")
+    inner = x0.numel() // n
+    out = torch.empty_like(eps)
+    check(lib().sf_add_noise(x0.data_ptr(), eps.data_ptr(), tt.data_ptr(), is64, sigmas.data_ptr(), timesteps.data_ptr(),
+                             sigmas.numel(), out.data_ptr(), n, inner, stream_handle()), "sf_add_noise")
+    return out

@@ -1,0 +1,245 @@
+"""`CausalInferencePipeline` -- drop-in for pipeline/causal_inference.py of the reference.
+
+Same constructor `(args, device, generator=None, text_encoder=None, vae=None)`, same
+`inference(noise, text_prompts, initial_latent=None, return_latents=False, profile=False,
+low_memory=False)`, same attributes read by the reference's other callers (`kv_cache1`,
+`crossattn_cache`, `denoising_step_list`, `scheduler`, `frame_seq_length`, `num_frame_per_block`,
+`num_transformer_blocks`; demo.py:309-404) and the same cache-dict schema.
+
+What differs: the five constants the reference hard-codes for Wan-1.3B/480p
+(30 blocks, 1560 tokens/frame, 12x128 heads, 32760-token cache; causal_inference.py:33-34,
+:288-293) are derived from the generator's shape and the latent size; the text encoder and VAE
+are outside this hot path and must be injected (a synthetic encoder / identity VAE live in
+`harness.py`); the per-step `print` is dropped; `low_memory` is accepted and ignored (288 GB HBM).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from .wan_wrapper import WanDiffusionWrapper
+
+
+class CausalInferencePipeline(torch.nn.Module):
+    def __init__(self, args, device, generator=None, text_encoder=None, vae=None):
+        super().__init__()
+        self.device_ = torch.device(device)
+        self.generator = WanDiffusionWrapper(**getattr(args, "model_kwargs", {}), is_causal=True, device=device) \
+            if generator is None else generator
+        if text_encoder is None or vae is None:
+            raise NotImplementedError(
+                "the umT5 text encoder and the Wan VAE are outside this hot path: inject text_encoder= and vae= "
+                "(see self_forcing_amd.harness.SyntheticTextEncoder / IdentityVAE)")
+        self.text_encoder = text_encoder
+        self.vae = vae
+
+        # causal hyper-parameters (causal_inference.py:25-45)
+        self.scheduler = self.generator.get_scheduler()
+        self.denoising_step_list = torch.tensor(args.denoising_step_list, dtype=torch.long)
+        if args.warp_denoising_step:
+            timesteps = torch.cat((self.scheduler.timesteps.cpu(), torch.tensor([0], dtype=torch.float32)))
+            self.denoising_step_list = timesteps[1000 - self.denoising_step_list]
+
+        self.num_transformer_blocks = self.generator.model.num_layers
+        self.frame_seq_length = 1560  # refined from the latent size at inference()
+        self.kv_cache1 = None
+        self.crossattn_cache = None
+        self.args = args
+        self.num_frame_per_block = getattr(args, "num_frame_per_block", 1)
+        self.independent_first_frame = args.independent_first_frame
+        self.local_attn_size = self.generator.model.local_attn_size
+        if self.num_frame_per_block > 1:
+            self.generator.model.num_frame_per_block = self.num_frame_per_block
+        # re-noise source; the reference calls torch.randn_like (causal_inference.py:208).  Tests and
+        # the CPU-baseline comparison inject pre-drawn tensors here so both sides consume the same eps.
+        self.noise_source: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+        self.last_profile = None
+        self._cache_key = None
+
+    # ------------------------------------------------------------------------------------------
+    def _randn_like(self, t: torch.Tensor) -> torch.Tensor:
+        if self.noise_source is not None:
+            return self.noise_source(t).to(device=t.device, dtype=t.dtype)
+        return torch.randn_like(t)
+
+    def inference(self, noise: torch.Tensor, text_prompts: List[str], initial_latent: Optional[torch.Tensor] = None,
+                  return_latents: bool = False, profile: bool = False, low_memory: bool = False):
+        """noise [B, F, C, H, W] -> video in [0, 1] (and the latents)."""
+        batch_size, num_frames, num_channels, height, width = noise.shape
+        if not self.independent_first_frame or (self.independent_first_frame and initial_latent is not None):
+            assert num_frames % self.num_frame_per_block == 0
+            num_blocks = num_frames // self.num_frame_per_block
+        else:
+            assert (num_frames - 1) % self.num_frame_per_block == 0
+            num_blocks = (num_frames - 1) // self.num_frame_per_block
+        num_input_frames = initial_latent.shape[1] if initial_latent is not None else 0
+        num_output_frames = num_frames + num_input_frames
+        self.frame_seq_length = (height // 2) * (width // 2)
+        conditional_dict = self.text_encoder(text_prompts=text_prompts)
+
+        output = torch.zeros([batch_size, num_output_frames, num_channels, height, width], device=noise.device, dtype=noise.dtype)
+
+        if profile:
+            ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+            init_start, init_end, diffusion_start, diffusion_end, vae_start, vae_end = ev(), ev(), ev(), ev(), ev(), ev()
+            block_events = []
+            init_start.record()
+
+        # Step 1: (re)initialise the caches (causal_inference.py:111-132)
+        key = (batch_size, self._cache_tokens(num_output_frames), noise.device)
+        if self.kv_cache1 is None or self._cache_key != key:
+            self._initialize_kv_cache(batch_size, noise.dtype, noise.device, cache_tokens=key[1])
+            self._initialize_crossattn_cache(batch_size, noise.dtype, noise.device)
+            self._cache_key = key
+        else:
+            for block_index in range(self.num_transformer_blocks):
+                self.crossattn_cache[block_index]["is_init"] = False
+            self._reset_kv_indices()
+
+        # Step 2: cache the context frames (causal_inference.py:134-169)
+        gen = self.generator
+        current_start_frame = 0
+        if initial_latent is not None:
+            timestep = torch.zeros([batch_size, 1], device=noise.device, dtype=torch.int64)
+            if self.independent_first_frame:
+                assert (num_input_frames - 1) % self.num_frame_per_block == 0
+                num_input_blocks = (num_input_frames - 1) // self.num_frame_per_block
+                output[:, :1] = initial_latent[:, :1]
+                gen(noisy_image_or_video=initial_latent[:, :1], conditional_dict=conditional_dict, timestep=timestep,
+                    kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
+                    current_start=current_start_frame * self.frame_seq_length)
+                current_start_frame += 1
+            else:
+                assert num_input_frames % self.num_frame_per_block == 0
+                num_input_blocks = num_input_frames // self.num_frame_per_block
+            for _ in range(num_input_blocks):
+                ref = initial_latent[:, current_start_frame:current_start_frame + self.num_frame_per_block]
+                output[:, current_start_frame:current_start_frame + self.num_frame_per_block] = ref
+                gen(noisy_image_or_video=ref, conditional_dict=conditional_dict, timestep=timestep,
+                    kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
+                    current_start=current_start_frame * self.frame_seq_length)
+                current_start_frame += self.num_frame_per_block
+
+        if profile:
+            init_end.record()
+            diffusion_start.record()
+
+        # Step 3: temporal denoising loop (causal_inference.py:176-244)
+        all_num_frames = [self.num_frame_per_block] * num_blocks
+        if self.independent_first_frame and initial_latent is None:
+            all_num_frames = [1] + all_num_frames
+        steps = self.denoising_step_list
+        ctx_noise = getattr(self.args, "context_noise", 0)
+        for current_num_frames in all_num_frames:
+            if profile:
+                bs, be = ev(), ev()
+                bs.record()
+            noisy_input = noise[:, current_start_frame - num_input_frames:
+                                current_start_frame + current_num_frames - num_input_frames]
+            start_tok = current_start_frame * self.frame_seq_length
+            for index, current_timestep in enumerate(steps):
+                timestep = torch.ones([batch_size, current_num_frames], device=noise.device, dtype=torch.int64) \
+                    * current_timestep.to(noise.device)
+                _, denoised_pred = gen(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
+                                       timestep=timestep, kv_cache=self.kv_cache1,
+                                       crossattn_cache=self.crossattn_cache, current_start=start_tok)
+                if index < len(steps) - 1:
+                    next_timestep = steps[index + 1].to(noise.device)
+                    flat = denoised_pred.flatten(0, 1)
+                    noisy_input = self.scheduler.add_noise(
+                        flat, self._randn_like(flat),
+                        next_timestep * torch.ones([batch_size * current_num_frames], device=noise.device, dtype=torch.long)
+                    ).unflatten(0, denoised_pred.shape[:2])
+
+            output[:, current_start_frame:current_start_frame + current_num_frames] = denoised_pred
+
+            # rerun at the context timestep so the cache holds clean K/V (causal_inference.py:226-235)
+            context_timestep = torch.ones_like(timestep) * ctx_noise
+            gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
+                kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok)
+            if profile:
+                be.record()
+                block_events.append((bs, be))
+            current_start_frame += current_num_frames
+
+        if profile:
+            diffusion_end.record()
+            vae_start.record()
+
+        # Step 4: decode (causal_inference.py:254-256)
+        video = self.vae.decode_to_pixel(output, use_cache=False)
+        video = (video * 0.5 + 0.5).clamp(0, 1)
+
+        if profile:
+            vae_end.record()
+            torch.cuda.synchronize()
+            init_time = init_start.elapsed_time(init_end)
+            diffusion_time = diffusion_start.elapsed_time(diffusion_end)
+            vae_time = vae_start.elapsed_time(vae_end)
+            blocks = [a.elapsed_time(b) for a, b in block_events]
+            total = init_time + diffusion_time + vae_time
+            self.last_profile = {"init_ms": init_time, "diffusion_ms": diffusion_time, "vae_ms": vae_time,
+                                 "block_ms": blocks, "total_ms": total}
+            print("Profiling results:")
+            print(f"  - Initialization/caching time: {init_time:.2f} ms ({100 * init_time / total:.2f}%)")
+            print(f"  - Diffusion generation time: {diffusion_time:.2f} ms ({100 * diffusion_time / total:.2f}%)")
+            for i, bt in enumerate(blocks):
+                print(f"    - Block {i} generation time: {bt:.2f} ms ({100 * bt / diffusion_time:.2f}% of diffusion)")
+            print(f"  - VAE decoding time: {vae_time:.2f} ms ({100 * vae_time / total:.2f}%)")
+            print(f"  - Total time: {total:.2f} ms")
+
+        if return_latents:
+            return video, output
+        return video
+
+    # ------------------------------------------------------------------------------------------
+    def _cache_tokens(self, total_frames: Optional[int] = None) -> int:
+        """Cache capacity in tokens.  The reference uses 32760 (= 21 frames x 1560) or
+        local_attn_size x 1560 (causal_inference.py:283-288); here: frames x tokens-per-frame of the
+        actual latent, never less than what the rollout needs."""
+        if self.local_attn_size != -1:
+            return self.local_attn_size * self.frame_seq_length
+        frames = max(21, total_frames or 0)
+        return frames * self.frame_seq_length
+
+    def _initialize_kv_cache(self, batch_size, dtype, device, cache_tokens: Optional[int] = None):
+        """Per-GPU KV cache, same dict schema as causal_inference.py:278-298.  The 2 x L index
+        tensors are views of one [L, 2] buffer so one fill updates them all."""
+        shape = self.generator.model.shape
+        if cache_tokens is None:
+            cache_tokens = self._cache_tokens()
+        n = self.num_transformer_blocks
+        index_buffer = torch.zeros(n, 2, dtype=torch.long, device=device)
+        kv_cache1 = []
+        for i in range(n):
+            kv_cache1.append({
+                "k": torch.zeros([batch_size, cache_tokens, shape.num_heads, shape.head_dim], dtype=dtype, device=device),
+                "v": torch.zeros([batch_size, cache_tokens, shape.num_heads, shape.head_dim], dtype=dtype, device=device),
+                "global_end_index": index_buffer[i, 0:1],
+                "local_end_index": index_buffer[i, 1:2],
+                "_sf_index_buffer": index_buffer,
+            })
+        kv_cache1[0]["_sf_mirror"] = (kv_cache1[0]["global_end_index"], kv_cache1[0]["local_end_index"], 0, 0)
+        self.kv_cache1 = kv_cache1
+
+    def _reset_kv_indices(self):
+        buf = self.kv_cache1[0].get("_sf_index_buffer")
+        if buf is not None:
+            buf.zero_()
+            d0 = self.kv_cache1[0]
+            d0["_sf_mirror"] = (d0["global_end_index"], d0["local_end_index"], 0, 0)
+        else:  # foreign cache: rebind as the reference does (causal_inference.py:128-132)
+            dev = self.kv_cache1[0]["k"].device
+            for kv in self.kv_cache1:
+                kv["global_end_index"] = torch.tensor([0], dtype=torch.long, device=dev)
+                kv["local_end_index"] = torch.tensor([0], dtype=torch.long, device=dev)
+
+    def _initialize_crossattn_cache(self, batch_size, dtype, device):
+        """causal_inference.py:300-312."""
+        shape = self.generator.model.shape
+        self.crossattn_cache = [{
+            "k": torch.zeros([batch_size, shape.text_len, shape.num_heads, shape.head_dim], dtype=dtype, device=device),
+            "v": torch.zeros([batch_size, shape.text_len, shape.num_heads, shape.head_dim], dtype=dtype, device=device),
+            "is_init": False,
+        } for _ in range(self.num_transformer_blocks)]

@@ -1,0 +1,208 @@
+"""`WanDiffusionWrapper` -- drop-in for the reference's generator wrapper on the KV-cached path.
+
+Mirrors utils/wan_wrapper.py:120-177, 253-349 of the reference: same constructor keywords, same
+`forward(noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache,
+current_start, ...) -> (flow_pred, pred_x0)`, same cache-dict schema (the callee mutates the
+caller's caches in place), `.scheduler`, `.get_scheduler()`, `.model.local_attn_size`,
+`.model.num_frame_per_block`.  Everything behind `forward` runs in the HIP kernels.
+
+Differences from the reference, all deliberate:
+  * weights: a local checkpoint directory (`model_path`) with `*.safetensors`, an explicit
+    `state_dict=`, or `random_init_seed=`; there is no implicit download and no silent random init;
+  * LoRA adapters present in a state dict are merged into the base matrices at load time;
+  * the attention window for `local_attn_size == -1` is the cache capacity and for rolling mode
+    `local_attn_size * frame_seqlen` of the CURRENT latent size (the reference hard-codes
+    32760 / `local_attn_size * 1560`, causal_model.py:77, which is only right for 60x104 latents);
+  * the non-cached branches (`kv_cache is None`, classify_mode, clean_x teacher forcing) and
+    `add_condition` belong to training / the pose fork and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .kvcache import plan_cache_update
+from .model import CausalWanModel
+from .scheduler import FlowMatchScheduler
+from .weights import NAMED_SHAPES, WanShape, merge_lora, strip_prefix, synth_state_dict
+
+Tensor = torch.Tensor
+
+
+def _load_checkpoint_dir(path: str) -> Dict[str, Tensor]:
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(
+            f"no *.safetensors under {path!r}. Pass state_dict=..., or random_init_seed=<int> for "
+            "seeded random weights (benchmarks / tests).")
+    from safetensors.torch import load_file
+    sd: Dict[str, Tensor] = {}
+    for f in files:
+        sd.update(load_file(f))
+    return sd
+
+
+class WanDiffusionWrapper(torch.nn.Module):
+    def __init__(self, model_name: str = "Wan2.1-T2V-1.3B", model_path: Optional[str] = None, timestep_shift: float = 8.0,
+                 is_causal: bool = False, local_attn_size: int = -1, sink_size: int = 0, lora_rank: Optional[int] = None,
+                 lora_alpha: float = 1.0, lora_dropout: float = 0.0, lora_targets: Optional[List[str]] = None,
+                 lora_path: Optional[str] = None, *, shape: Optional[WanShape] = None,
+                 state_dict: Optional[Dict[str, Tensor]] = None, random_init_seed: Optional[int] = None,
+                 device="cuda"):
+        super().__init__()
+        if not is_causal:
+            raise NotImplementedError("only the causal (KV-cached) generator is implemented on this path")
+        if shape is None:
+            if model_name not in NAMED_SHAPES:
+                raise ValueError(f"unknown model_name {model_name!r}; pass shape=WanShape(...)")
+            shape = NAMED_SHAPES[model_name]
+        shape = shape.replace(local_attn_size=local_attn_size, sink_size=sink_size)
+        if state_dict is None:
+            if random_init_seed is not None:
+                state_dict = synth_state_dict(shape, seed=random_init_seed)
+            else:
+                state_dict = _load_checkpoint_dir(model_path or f"wan_models/{model_name}/")
+        state_dict = strip_prefix(state_dict)
+        if any(".lora_A." in k for k in state_dict):
+            if not lora_rank:
+                raise ValueError("state dict holds LoRA adapters but lora_rank was not given")
+            state_dict = merge_lora(state_dict, alpha=lora_alpha, rank=lora_rank)
+        if lora_path is not None:
+            raise NotImplementedError("separate LoRA files: merge them offline and pass the merged state_dict")
+
+        self.uniform_timestep = not is_causal
+        self.scheduler = FlowMatchScheduler(shift=timestep_shift, sigma_min=0.0, extra_one_step=True)
+        self.scheduler.set_timesteps(1000, training=True)
+        self.model = CausalWanModel(shape, state_dict, device, self.scheduler.sigmas, self.scheduler.timesteps)
+        self.seq_len = 32760
+        self._ptr_cache: Dict[int, tuple] = {}
+        self._evict_scratch: Optional[Tensor] = None
+
+    # --- reference API ------------------------------------------------------------------------
+    def get_scheduler(self):
+        return self.scheduler
+
+    def post_init(self):
+        self.get_scheduler()
+
+    def enable_gradient_checkpointing(self):
+        raise NotImplementedError("inference-only path")
+
+    # --- cache plumbing -----------------------------------------------------------------------
+    @staticmethod
+    def _read_indices(kv_cache: List[dict]):
+        """Host values of (global_end, local_end).  The pipeline's integers are mirrored in the
+        first layer's dict; a mirror is valid only while the dict still holds the very index
+        tensors we last updated (the reference's reset REBINDS them, causal_inference.py:128-132)."""
+        d = kv_cache[0]
+        mir = d.get("_sf_mirror")
+        if mir is not None and mir[0] is d["global_end_index"] and mir[1] is d["local_end_index"]:
+            return mir[2], mir[3]
+        return int(d["global_end_index"].item()), int(d["local_end_index"].item())
+
+    @staticmethod
+    def _write_indices(kv_cache: List[dict], global_end: int, local_end: int) -> None:
+        d0 = kv_cache[0]
+        buf = d0.get("_sf_index_buffer")
+        if buf is not None and all(kv.get("_sf_index_buffer") is buf for kv in kv_cache) and \
+                d0["global_end_index"].data_ptr() == buf.data_ptr():
+            # all layers' index tensors are views of one buffer [L, 2]: two fills update them all
+            buf[:, 0].fill_(global_end)
+            buf[:, 1].fill_(local_end)
+        else:
+            for kv in kv_cache:
+                kv["global_end_index"].fill_(global_end)
+                kv["local_end_index"].fill_(local_end)
+        d0["_sf_mirror"] = (d0["global_end_index"], d0["local_end_index"], global_end, local_end)
+
+    def _pointer_tables(self, kv_cache: List[dict], crossattn_cache: List[dict]):
+        L = self.model.num_layers
+        key = tuple(kv["k"].data_ptr() for kv in kv_cache) + tuple(c["k"].data_ptr() for c in crossattn_cache) + \
+            tuple(kv["v"].data_ptr() for kv in kv_cache) + tuple(c["v"].data_ptr() for c in crossattn_cache)
+        hit = self._ptr_cache.get("tables")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
+        tabs = (arr([kv["k"] for kv in kv_cache]), arr([kv["v"] for kv in kv_cache]),
+                arr([c["k"] for c in crossattn_cache]), arr([c["v"] for c in crossattn_cache]))
+        self._ptr_cache["tables"] = (key, tabs)
+        return tabs
+
+    # --- the hot call --------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, noisy_image_or_video: Tensor, conditional_dict: dict, timestep: Tensor,
+                kv_cache: Optional[List[dict]] = None, crossattn_cache: Optional[List[dict]] = None,
+                current_start: Optional[int] = None, classify_mode: Optional[bool] = False,
+                concat_time_embeddings: Optional[bool] = False, clean_x: Optional[Tensor] = None,
+                aug_t: Optional[Tensor] = None, cache_start: Optional[int] = None,
+                add_condition: Optional[Tensor] = None, clip_feature: Optional[Tensor] = None, y: Optional[Tensor] = None):
+        if kv_cache is None or crossattn_cache is None:
+            raise NotImplementedError("only the KV-cached inference branch is implemented (kv_cache / crossattn_cache required)")
+        if classify_mode or clean_x is not None or aug_t is not None:
+            raise NotImplementedError("training-only branches (classify_mode / teacher forcing) are out of scope")
+        if add_condition is None:
+            add_condition = conditional_dict.get("add_condition")
+        if add_condition is not None or clip_feature is not None or y is not None \
+                or conditional_dict.get("clip_feature") is not None or conditional_dict.get("y") is not None:
+            raise NotImplementedError("pose / image conditioning (add_condition, clip_feature, y) is not implemented yet")
+        mdl = self.model
+        shape = mdl.shape
+        x = noisy_image_or_video
+        assert x.dim() == 5, "noisy_image_or_video must be [B, F, C, H, W]"
+        B, F, Cin, H, W = x.shape
+        assert Cin == shape.in_dim, f"expected {shape.in_dim} latent channels, got {Cin}"
+        assert len(kv_cache) == mdl.num_layers and len(crossattn_cache) == mdl.num_layers, \
+            "cache lists must have one entry per transformer block"
+        if current_start is None:
+            current_start = 0
+        x = x.to(device=mdl.device, dtype=torch.bfloat16).contiguous()
+        t = timestep.to(mdl.device)
+        if t.dim() == 1:
+            t = t.unsqueeze(1)
+        t = (t if t.dtype == torch.int64 else t.to(torch.float32)).contiguous()
+        assert t.shape[0] == B, "timestep must be [B, groups]"
+
+        fs = (H // 2) * (W // 2)
+        n_new = F * fs
+        cap = kv_cache[0]["k"].shape[1]
+        k0 = kv_cache[0]["k"]
+        assert tuple(k0.shape) == (B, cap, shape.num_heads, shape.head_dim) and k0.dtype == torch.bfloat16 and k0.is_contiguous(), \
+            f"kv cache must be contiguous bf16 [B, S, {shape.num_heads}, {shape.head_dim}], got {tuple(k0.shape)} {k0.dtype}"
+        c0 = crossattn_cache[0]["k"]
+        assert tuple(c0.shape) == (B, shape.text_len, shape.num_heads, shape.head_dim) and c0.is_contiguous(), \
+            f"cross-attention cache must be [B, {shape.text_len}, {shape.num_heads}, {shape.head_dim}]"
+
+        global_end, local_end = self._read_indices(kv_cache)
+        window = cap if mdl.local_attn_size == -1 else mdl.local_attn_size * fs
+        plan = plan_cache_update(local_end, global_end, current_start, n_new, cap, mdl.local_attn_size,
+                                 mdl.sink_size * fs, window)
+        scratch = None
+        if plan.evict > 0:
+            need = B * plan.keep * shape.dim * 2
+            if self._evict_scratch is None or self._evict_scratch.numel() < need:
+                self._evict_scratch = torch.empty(B * cap * shape.dim * 2, dtype=torch.uint8, device=mdl.device)
+            scratch = self._evict_scratch
+
+        init_cross = not crossattn_cache[0]["is_init"]
+        pe = None
+        if init_cross:
+            pe = conditional_dict["prompt_embeds"].to(device=mdl.device, dtype=torch.bfloat16)
+            assert pe.dim() == 3 and pe.shape[0] == B and pe.shape[2] == shape.text_dim and pe.shape[1] <= shape.text_len, \
+                f"prompt_embeds must be [B, <= {shape.text_len}, {shape.text_dim}], got {tuple(pe.shape)}"
+            if pe.shape[1] < shape.text_len:  # zero-pad to text_len (causal_model.py:838-842)
+                pe = torch.cat([pe, pe.new_zeros(B, shape.text_len - pe.shape[1], shape.text_dim)], dim=1)
+            pe = pe.contiguous()
+
+        k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = self._pointer_tables(kv_cache, crossattn_cache)
+        flow, x0 = mdl.forward(x, t, pe, init_cross, k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cap, plan,
+                               current_start // fs, scratch)
+        if init_cross:
+            for c in crossattn_cache:
+                c["is_init"] = True
+        self._write_indices(kv_cache, plan.global_end, plan.local_end)
+        return flow, x0

@@ -1,0 +1,262 @@
+"""GPU parity tests, per kernel: the HIP path (through the C-ABI) against the CPU oracle /
+the golden vectors generated from the reference.  Run with `-m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import self_forcing_amd as sfa
+from self_forcing_amd import ops
+from oracle import wan_oracle as wo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def bf(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def T(a, dtype=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def opsgold():
+    return np.load(os.path.join(GOLD, "ops.npz"))
+
+
+# ---------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (72, 64, 64), (200, 256, 128), (257, 384, 1536), (1560, 1536, 512),
+                                   (4680, 512, 1024)])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid", "gate_resid"])
+def test_gemm(M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a, w = bf((M, K), g), bf((N, K), g, 1.0 / K ** 0.5)
+    bias = bf((N,), g, 0.5)
+    resid = bf((M, N), g)
+    groups = 3 if M % 3 == 0 else 1
+    gate_mod, e0 = bf((N,), g, 0.5), bf((groups, 6, N), g, 0.5)
+    y = a.float() @ w.float().t() + bias.float()
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(y, approximate="tanh")
+    elif epi == "resid":
+        ref = resid.float() + y
+    elif epi == "gate_resid":
+        gate = (gate_mod.float()[None] + e0[:, 2].float()).to(torch.bfloat16).float()   # [groups, N]
+        ref = resid.float() + y * gate.repeat_interleave(M // groups, dim=0)
+    else:
+        ref = y
+    kw = {}
+    if epi in ("resid", "gate_resid"):
+        kw["resid"] = resid.to(DEV)
+    if epi == "gate_resid":
+        kw.update(gate_mod=gate_mod.to(DEV), gate_e0=e0.to(DEV)[:, 2], rows_per_group=M // groups)
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), epilogue=epi, **kw)
+    # one bf16 rounding of an fp32-accumulated result: <= 2^-9 relative per element
+    assert rel(out, ref) < 4e-3
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_gemm_inplace_residual_and_strides():
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 256, 192
+    a_full = bf((M, K + 64), g).to(DEV)
+    a = a_full[:, :K]                      # row stride K+64
+    w, x = bf((N, K), g, 0.1).to(DEV), bf((M, N), g).to(DEV)
+    ref = x.float() + a.float() @ w.float().t()
+    ops.gemm(a, w, None, epilogue="resid", resid=x, out=x)   # out aliases resid
+    assert rel(x, ref) < 4e-3
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(16, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(sfa._lib.SfHipError):
+        ops.gemm(a, w)          # K not a multiple of 64
+    with pytest.raises(ValueError):
+        ops.gemm(a.float(), w)  # wrong dtype
+
+
+# ----------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 32, 64), (1, 2, 100, 200), (2, 3, 130, 24), (1, 4, 24, 512),
+                                        (1, 2, 1560, 4680), (1, 1, 200, 1561)])
+def test_attention(B, H, Lq, Lk):
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g), bf((B, Lk, H, 128), g)
+    ref = wo.sdpa(q.float(), k.float(), v.float())
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    # P is rounded to bf16 before P.V (as flash-attn does) and the output once more
+    assert rel(out, ref) < 6e-3
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump late: one key far along the sequence dominates one query
+    (cdna guide rule 26: a rescale branch needs an input that takes it)."""
+    g = torch.Generator().manual_seed(11)
+    B, H, Lq, Lk = 1, 1, 64, 448
+    q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g, 0.2), bf((B, Lk, H, 128), g)
+    k[0, 400, 0] = (q[0, 5, 0].float() * 3).to(torch.bfloat16)     # spike in the 7th tile
+    k[0, 3, 0] = (q[0, 9, 0].float() * 2).to(torch.bfloat16)       # and one in the first
+    ref = wo.sdpa(q.float(), k.float(), v.float())
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert rel(out, ref) < 6e-3
+    assert (out.float().cpu() - ref).abs().max() < 3e-2
+
+
+def test_attention_strided_cache_window():
+    """K/V as a window [start:end) of a larger cache, Q/K/V token-major with all heads interleaved
+    (the layout of the KV cache, pipeline/causal_inference.py:288-293)."""
+    g = torch.Generator().manual_seed(12)
+    B, H, S = 2, 3, 300
+    kc, vc = bf((B, S, H, 128), g).to(DEV), bf((B, S, H, 128), g).to(DEV)
+    q = bf((B, 70, H, 128), g).to(DEV)
+    out = ops.attention(q, kc[:, 37:250], vc[:, 37:250])
+    ref = wo.sdpa(q.float().cpu(), kc[:, 37:250].float().cpu(), vc[:, 37:250].float().cpu())
+    assert rel(out, ref) < 6e-3
+
+
+# ------------------------------------------------------------------------- norms / rope / cache
+@pytest.mark.parametrize("C", [512, 1536, 5120])
+def test_layernorm_modulate_and_affine(C):
+    g = torch.Generator().manual_seed(C)
+    M, G = 96, 3
+    x = bf((M, C), g, 2.0)
+    mod, e0 = bf((6, C), g, 0.3), bf((G, 6, C), g, 0.3)
+    e = (mod.float()[None] + e0.float()).to(torch.bfloat16).float()           # [G, 6, C]
+    ln = wo.layer_norm(x.float(), 1e-6)
+    ref = ln.view(G, M // G, C) * (1 + e[:, 1:2]) + e[:, 0:1]
+    e0d = e0.to(DEV)
+    out = ops.layernorm_modulate(x.to(DEV), mod[0].to(DEV), mod[1].to(DEV), e0d[:, 0], e0d[:, 1], M // G)
+    assert rel(out, ref.reshape(M, C)) < 3e-3
+    w, b = bf((C,), g), bf((C,), g)
+    out2 = ops.layernorm_affine(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert rel(out2, wo.layer_norm(x.float(), 1e-6, w.float(), b.float())) < 3e-3
+
+
+def test_rmsnorm_golden(opsgold):
+    x, w = T(opsgold["rms_x"]).bfloat16(), T(opsgold["rms_w"]).bfloat16()
+    out = ops.rmsnorm(x.to(DEV), w.to(DEV))
+    # same rounding points as the reference -> equal up to 1 bf16 ulp on a few elements
+    ref = T(opsgold["rms_out_bf16"])
+    assert rel(out, ref) < 2e-3
+    assert (out.float().cpu() != ref).float().mean() < 0.02
+
+
+def test_qkv_norm_rope_cache_vs_oracle():
+    g = torch.Generator().manual_seed(21)
+    B, f, h, w, H = 2, 2, 4, 6, 4
+    C, L, S = H * 128, f * h * w, 100
+    qkv = bf((B * L, 3 * C), g)
+    wq, wk = (1 + 0.1 * torch.randn(C, generator=g)).to(torch.bfloat16), (1 + 0.1 * torch.randn(C, generator=g)).to(torch.bfloat16)
+    kc = torch.zeros(B, S, H, 128, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    cos, sin = sfa.model.rope_tables(128)
+    start_frame, write_start = 5, 31
+    q = ops.qkv_norm_rope_cache(qkv.to(DEV), wq.to(DEV), wk.to(DEV), kc, vc, cos.to(DEV), sin.to(DEV), (f, h, w),
+                                write_start, start_frame)
+    rc, rs, split = wo.rope_tables(128)
+    x = qkv.view(B, L, 3, C)
+    qr = wo.causal_rope_apply(wo.rms_norm(x[:, :, 0], wq, 1e-6).view(B, L, H, 128), (f, h, w), rc, rs, split, start_frame)
+    kr = wo.causal_rope_apply(wo.rms_norm(x[:, :, 1], wk, 1e-6).view(B, L, H, 128), (f, h, w), rc, rs, split, start_frame)
+    # bf16 oracle mode has the same rounding points; allow 1-ulp flips from fp32-vs-fp64 rotation
+    assert rel(q.view(B, L, H, 128), qr.float()) < 2e-3
+    assert (q.view(B, L, H, 128).cpu() != qr).float().mean() < 0.02
+    assert rel(kc[:, write_start:write_start + L], kr.float()) < 2e-3
+    assert torch.equal(vc[:, write_start:write_start + L].cpu(), x[:, :, 2].reshape(B, L, H, 128))
+    assert kc[:, :write_start].abs().sum() == 0 and kc[:, write_start + L:].abs().sum() == 0
+
+
+def test_qkv_norm_rope_cache_overflow_raises():
+    C = 512
+    qkv = torch.zeros(24, 3 * C, dtype=torch.bfloat16, device=DEV)
+    w = torch.ones(C, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(1, 30, 4, 128, dtype=torch.bfloat16, device=DEV)
+    cos, sin = sfa.model.rope_tables(128)
+    with pytest.raises(sfa._lib.SfHipError, match="overflow"):
+        ops.qkv_norm_rope_cache(qkv, w, w, kc, kc.clone(), cos.to(DEV), sin.to(DEV), (1, 4, 6), 10, 0)
+
+
+def test_kv_evict():
+    g = torch.Generator().manual_seed(4)
+    B, S, H = 2, 40, 4
+    cache = bf((B, S, H, 128), g).to(DEV)
+    ref = cache.clone()
+    sink, evict, keep = 8, 6, 20
+    ref[:, sink:sink + keep] = cache[:, sink + evict:sink + evict + keep].clone()
+    scratch = torch.empty(B * keep * H * 128 * 2, dtype=torch.uint8, device=DEV)
+    ops.kv_evict(cache, sink, evict, keep, scratch)
+    assert torch.equal(cache, ref)
+
+
+# ----------------------------------------------------------------------- small kernels, golden
+def test_sinusoid_golden(opsgold):
+    t = T(opsgold["sinus_t"], torch.float64).float()
+    out = ops.sinusoid_embedding(t.to(DEV), 256)
+    ref = T(opsgold["sinus_out"], torch.float64).to(torch.bfloat16)
+    # device fp64 cos/sin/pow vs the host's: equal except rare last-bit ties
+    assert (out.cpu() != ref).float().mean() < 0.005
+    assert (out.float().cpu() - ref.float()).abs().max() < 1e-2
+    ti = torch.tensor([0, 250, 1000], dtype=torch.int64)
+    outi = ops.sinusoid_embedding(ti.to(DEV), 256)
+    refi = wo.sinusoidal_embedding_1d(256, ti).to(torch.bfloat16)
+    assert (outi.cpu() != refi).float().mean() < 0.005
+
+
+def test_small_linear():
+    g = torch.Generator().manual_seed(8)
+    for M, N, K, ai, ao in [(3, 1536, 256, None, "silu"), (1, 512, 512, None, None), (21, 9216 // 4, 1536, "silu", None),
+                            (7, 130, 64, "silu", "gelu")]:
+        x, w, b = bf((M, K), g), bf((N, K), g, 0.05), bf((N,), g, 0.1)
+        xin = torch.nn.functional.silu(x.float()).to(torch.bfloat16).float() if ai == "silu" else x.float()
+        y = xin @ w.float().t() + b.float()
+        if ao == "silu":
+            y = torch.nn.functional.silu(y)
+        elif ao == "gelu":
+            y = torch.nn.functional.gelu(y, approximate="tanh")
+        out = ops.small_linear(x.to(DEV), w.to(DEV), b.to(DEV), ai, ao)
+        assert rel(out, y) < 4e-3, (M, N, K)
+
+
+def test_patchify_gemm_matches_conv_golden():
+    mods = np.load(os.path.join(GOLD, "modules_reduced.npz"))
+    sd = sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0)
+    x = T(mods["pe_x"]).bfloat16()                       # [1, 16, 2, 8, 12] (model layout: C before F)
+    cols = ops.patchify(x.permute(0, 2, 1, 3, 4).contiguous().to(DEV))
+    tok = ops.gemm(cols, sd["patch_embedding.weight"].flatten(1).to(DEV), sd["patch_embedding.bias"].to(DEV))
+    assert rel(tok, T(mods["pe_out_f32"])[0]) < 4e-3
+
+
+def test_unpatchify_x0_golden(opsgold):
+    mods = np.load(os.path.join(GOLD, "modules_reduced.npz"))
+    sched = wo.FlowMatchTables(5.0)
+    hx = T(mods["unp_x"]).bfloat16()                     # [2*24, 64]
+    g = torch.Generator().manual_seed(2)
+    xt = bf((1, 2, 16, 8, 12), g)
+    ts = torch.tensor([[937.5, 625.0]], dtype=torch.float32)
+    flow, x0 = ops.unpatchify_x0(hx.to(DEV), xt.to(DEV), ts.to(DEV), sched.sigmas.to(DEV), sched.timesteps.to(DEV))
+    ref_flow = T(mods["unp_out_bf16"]).permute(1, 0, 2, 3)[None]          # [16,2,8,12] -> [1,2,16,8,12]
+    assert torch.equal(flow.float().cpu(), ref_flow)
+    ref_x0 = wo.flow_to_x0(sched, ref_flow[0].bfloat16(), xt[0], ts[0])
+    assert torch.equal(x0[0].cpu(), ref_x0)              # fp64 math, one rounding: bit exact
+    # one modulation group for both frames: a single sigma is broadcast
+    flow1, x01 = ops.unpatchify_x0(hx.to(DEV), xt.to(DEV), ts[:, :1].to(DEV), sched.sigmas.to(DEV), sched.timesteps.to(DEV))
+    ref1 = wo.flow_to_x0(sched, ref_flow[0].bfloat16(), xt[0], ts[0, :1].repeat(2))
+    assert torch.equal(x01[0].cpu(), ref1)
+
+
+def test_add_noise_golden(opsgold):
+    sched = wo.FlowMatchTables(5.0)
+    x0, eps, t = T(opsgold["an_x0"]).bfloat16(), T(opsgold["an_eps"]).bfloat16(), T(opsgold["an_t"])
+    out = ops.add_noise(x0.to(DEV), eps.to(DEV), t.to(DEV), sched.sigmas.to(DEV), sched.timesteps.to(DEV))
+    assert torch.equal(out.float().cpu(), T(opsgold["an_out_bf16"]))
+    ti = torch.from_numpy(opsgold["x0_ti"])
+    outi = ops.add_noise(x0.to(DEV), eps.to(DEV), ti.to(DEV), sched.sigmas.to(DEV), sched.timesteps.to(DEV))
+    assert torch.equal(outi.float().cpu(), T(opsgold["an_out_int_bf16"]))
