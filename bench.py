@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""Benchmark of the Self-Forcing hot path on MI355X: decoded frames / s / node for the
+chunk-wise autoregressive 4-step rollout (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full rollout of ONE prompt through `CausalInferencePipeline.inference`:
+Wan2.1-T2V-1.3B-shape random-init weights, 832x480 (latent 60x104), 21 latent = 81 decoded frames,
+3 frames per chunk, 4 warped denoising steps + 1 context pass per chunk = 35 DiT forwards,
+synthetic T5 embeddings resident in HBM (BASELINE.json configs[1], "S1").  With N > 1 (launched by
+torch.distributed.run, one process per GPU) every rank rolls out its own prompts
+(`rank, rank + N, ...`, the reference's DistributedSampler assignment, inference.py:96-100); RCCL
+carries only a weight-checksum all-reduce, barriers and the timing reduction -> weak scaling.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel (self-attention over the KV cache): algorithmic FLOPs per
+                  launch / its average launch duration, measured here with events on the launch
+                  stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline -- the CPU oracle (oracle/wan_oracle.py, bf16 mode = the reference's CPU path)
+                  timed on this host's cores on a bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import self_forcing_amd as sfa  # noqa: E402
+from self_forcing_amd import ops  # noqa: E402
+from self_forcing_amd.sharding import shard_indices  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+LAT_H, LAT_W = 60, 104
+DECODED_PER_LATENT = lambda f: 1 + 4 * (f - 1)  # noqa: E731  (Wan VAE temporal stride 4)
+
+
+def log(msg):
+    """progress on stderr (the JSON line on stdout stays alone)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def rollout_flops(shape, frames, nfpb, n_steps, fs):
+    """Algorithmic FLOPs of one rollout: linear + cross-attn per token, self-attn
+    4*C*N*Lk per layer per forward; (n_steps + 1) forwards per chunk."""
+    C, Fd, L = shape.dim, shape.ffn_dim, shape.num_layers
+    per_tok = L * (12 * C * C + 4 * C * Fd + 4 * shape.text_len * C) + 2 * 64 * C + 2 * C * 64
+    total = 0.0
+    n = nfpb * fs
+    for chunk in range(frames // nfpb):
+        lk = (chunk + 1) * n
+        total += (n_steps + 1) * (per_tok * n + L * 4.0 * C * n * lk)
+    return total
+
+
+def time_kernel(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()          # recorded on torch's current stream = the stream the C-ABI launches on
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+def roofline_leg(shape, dev, frames, nfpb, fs):
+    """Average launch duration of the self-attention kernel over the Lk values one rollout visits
+    (each chunk index launches it equally often), and of the biggest GEMM, from events on the
+    launch stream."""
+    H = shape.num_heads
+    n = nfpb * fs
+    g = torch.Generator(device="cpu").manual_seed(1)
+    q = torch.randn(1, n, H, 128, generator=g).to(torch.bfloat16).to(dev)
+    lk_max = frames * fs
+    k = torch.randn(1, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
+    v = torch.randn(1, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
+    durs, flops = [], []
+    for chunk in range(frames // nfpb):
+        lk = (chunk + 1) * n
+        ms = time_kernel(lambda: ops.attention(q, k[:, :lk], v[:, :lk]), 10)
+        durs.append(ms)
+        flops.append(4.0 * shape.dim * n * lk)
+    avg_ms = sum(durs) / len(durs)
+    avg_flops = sum(flops) / len(flops)
+    att = {"bound": "mfma", "kernel": "attention_kernel<0> (self-attention over the KV cache)",
+           "achieved": avg_flops / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+           "avg_launch_ms": avg_ms, "flops_per_launch": avg_flops,
+           "per_lk_tflops": {str((i + 1) * n): flops[i] / (durs[i] * 1e-3) / 1e12 for i in range(len(durs))}}
+    # GEMMs: ffn.0 (N = ffn_dim) and ffn.2 (K = ffn_dim) at M = n
+    a = torch.randn(n, shape.dim, generator=g).to(torch.bfloat16).to(dev)
+    w1 = (torch.randn(shape.ffn_dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+    b1 = torch.zeros(shape.ffn_dim, dtype=torch.bfloat16, device=dev)
+    hbuf = torch.empty(n, shape.ffn_dim, dtype=torch.bfloat16, device=dev)
+    ms1 = time_kernel(lambda: ops.gemm(a, w1, b1, epilogue="gelu", out=hbuf), 20)
+    w2 = (torch.randn(shape.dim, shape.ffn_dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+    b2 = torch.zeros(shape.dim, dtype=torch.bfloat16, device=dev)
+    o2 = torch.empty(n, shape.dim, dtype=torch.bfloat16, device=dev)
+    ms2 = time_kernel(lambda: ops.gemm(hbuf, w2, b2, out=o2), 20)
+    fl = 2.0 * n * shape.dim * shape.ffn_dim
+    gemm = {"ffn0_tflops": fl / (ms1 * 1e-3) / 1e12, "ffn2_tflops": fl / (ms2 * 1e-3) / 1e12,
+            "ffn0_ms": ms1, "ffn2_ms": ms2, "M": n, "C": shape.dim, "ffn": shape.ffn_dim}
+    return att, gemm
+
+
+def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
+    """The CPU oracle in bf16 mode (the reference's CPU path: bf16 weights, SDPA-style attention)
+    on this host's cores: ONE forward of `frames_sample` latent frames against an empty cache."""
+    from oracle import wan_oracle as wo
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle forward on {cores} host threads")
+    W = wo.prepare_weights(sd, torch.bfloat16)
+    cfg = wo.OracleConfig(dim=shape.dim, ffn_dim=shape.ffn_dim, num_heads=shape.num_heads, num_layers=shape.num_layers,
+                          text_dim=shape.text_dim)
+    fs = (LAT_H // 2) * (LAT_W // 2)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, frames_sample, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16)
+    pe = torch.randn(1, 512, shape.text_dim, generator=g).to(torch.bfloat16)
+    kv = wo.init_kv_cache(cfg, 1, frames_sample * fs, torch.bfloat16)
+    ca = wo.init_crossattn_cache(cfg, 1, torch.bfloat16)
+    sched = wo.FlowMatchTables(5.0)
+    ts = torch.full((1, frames_sample), 937.5)
+    with torch.no_grad():
+        t0 = time.time()
+        wo.wrapper_forward(W, cfg, sched, x, pe, ts, kv, ca, 0)
+        dt = time.time() - t0
+    # optimistic extrapolation: every one of the rollout's forwards costs what this empty-cache one does
+    n_fwd = (total_frames // nfpb) * (n_steps + 1) * (nfpb / frames_sample)
+    fps = DECODED_PER_LATENT(total_frames) / (n_fwd * dt)
+    return {"value": fps, "unit": "decoded frames/s (upper bound, extrapolated)", "cores": cores, "kind": "port",
+            "sample": f"1 DiT forward, {frames_sample} latent frame(s) = {frames_sample * fs} tokens, empty KV cache, bf16, "
+                      f"{dt:.2f} s; rollout = {n_fwd:.0f} such forwards with growing cache (so the true CPU rate is lower)",
+            "forward_seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=21, help="latent frames per rollout")
+    ap.add_argument("--model", default="Wan2.1-T2V-1.3B")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="print the pipeline's per-chunk event timing")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+
+    torch.set_num_threads(min(usable_cores(), 16))
+    log(f"rank {rank}/{world} on {dev}; synthesising weights")
+    shape = sfa.NAMED_SHAPES[a.model]
+    nfpb, step_list, shift = 3, [1000, 750, 500, 250], 5.0      # configs/self_forcing_dmd.yaml:9-18,56,69-70
+    fs = (LAT_H // 2) * (LAT_W // 2)
+    sd = sfa.synth_state_dict(shape, seed=0)                    # identical on every rank
+    args = SimpleNamespace(denoising_step_list=step_list, warp_denoising_step=True, independent_first_frame=False,
+                           num_frame_per_block=nfpb, context_noise=0)
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=shift, is_causal=True, device=dev)
+    enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=dev)
+    pipe = sfa.CausalInferencePipeline(args, dev, generator=gen, text_encoder=enc, vae=sfa.IdentityVAE())
+
+    if dist is not None:  # every rank must hold the same replica: compare a checksum over RCCL
+        cs = torch.stack([t.float().sum() for t in gen.model._keep[:64]]).sum().reshape(1).double()
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert lo.item() == hi.item(), "weight replicas differ across ranks"
+
+    total = a.warmup + a.steps
+    idx = shard_indices(total * world, rank, world)             # rank r: r, r + W, r + 2W, ...
+    prompts = [f"synthetic MovieGenVideoBench prompt #{i}" for i in idx]
+    for p in prompts:
+        enc([p])                                                # embeddings resident in HBM before timing
+    torch.manual_seed(0 + rank)                                 # set_seed(seed + rank), inference.py:45
+
+    def one_step(i):
+        noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
+        return pipe.inference(noise, [prompts[i]], return_latents=True, profile=a.profile and rank == 0)[1]
+
+    log(f"model resident ({gen.model.param_bytes() / 1e9:.2f} GB); warmup x{a.warmup}")
+    for i in range(a.warmup):
+        tw = time.perf_counter()
+        one_step(i)
+        torch.cuda.synchronize()
+        log(f"warmup step {i}: {time.perf_counter() - tw:.2f} s")
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total):
+        lat = one_step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log(f"timed {a.steps} steps in {elapsed:.2f} s")
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(lat.float()).all(), "non-finite latents"
+
+    decoded = DECODED_PER_LATENT(a.frames)
+    fps = world * a.steps * decoded / elapsed
+    flops = rollout_flops(shape, a.frames, nfpb, len(step_list), fs)
+    out = {
+        "metric": "decoded frames/sec/node, Wan-1.3B 832x480 4-step AR rollout",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"S1: {a.model}-shape random-init weights, latent {a.frames}x16x{LAT_H}x{LAT_W} "
+                               f"({decoded} decoded frames), {nfpb} frames/chunk, steps {step_list} warped (shift {shift}) "
+                               f"+ 1 context pass per chunk, batch 1 per GPU, prompts sharded rank::N",
+                   "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
+                   "parallelism": f"prompt-sharded x{world}"},
+        "algorithmic_tflop_per_step": flops / 1e12,
+        "achieved_tflops_per_gpu": flops * a.steps / elapsed / 1e12,
+        "mfma_frac_end_to_end": flops * a.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
+    }
+    if rank == 0 and not a.no_roofline:
+        log("roofline leg")
+        att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs)
+        out["roofline"] = att
+        out["gemm"] = gemm
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(shape, sd, 1, nfpb, len(step_list), a.frames)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,9 @@ __device__ __forceinline__ bf16x4 lds_tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
 }
 
+// KIND only gives self-attention (0: keys = the KV cache) and cross-attention (1: keys = the text
+// context) distinct symbols, so per-kernel profiles do not mix a 32760-key launch with a 512-key one.
+template <int KIND>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -256,7 +259,10 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
   const long nwg = (long)p.q_tiles * H * B;
   SF_CHECK(nwg < (1L << 30), "sf_attention: grid too large");
-  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)nwg), dim3(ATT_THREADS), ATT_LDS, (hipStream_t)stream, p);
+  if (Lk > 1024)
+    hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)nwg), dim3(ATT_THREADS), ATT_LDS, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)nwg), dim3(ATT_THREADS), ATT_LDS, (hipStream_t)stream, p);
   SF_HIP_LAUNCH_CHECK("sf_attention");
   return 0;
 }

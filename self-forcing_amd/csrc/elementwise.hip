@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void unpatchify_x0_kernel(const bf16_t* __rest
                                                             const float* __restrict__ sigmas, const float* __restrict__ timesteps,
                                                             int n_table, bf16_t* __restrict__ flow, bf16_t* __restrict__ x0,
                                                             int F, int groups, int Cout, int H, int W) {
+#pragma clang fp contract(off)  // xt - sigma*flow as a rounded product then a subtraction (fp64)
   const int bf = blockIdx.y;
   const int b = bf / F, f = bf - b * F;
   const int grp = f / (F / groups);
@@ -275,8 +276,8 @@ __global__ __launch_bounds__(256) void unpatchify_x0_kernel(const bf16_t* __rest
     *reinterpret_cast<bf16x2*>(flow + o) = fo;
     const bf16x2 xv = *reinterpret_cast<const bf16x2*>(xt + o);
     bf16x2 xo;
-    xo[0] = double_to_bf16(__dsub_rn((double)(float)xv[0], __dmul_rn(sigma, (double)(float)f0)));
-    xo[1] = double_to_bf16(__dsub_rn((double)(float)xv[1], __dmul_rn(sigma, (double)(float)f1)));
+    xo[0] = double_to_bf16((double)(float)xv[0] - sigma * (double)(float)f0);
+    xo[1] = double_to_bf16((double)(float)xv[1] - sigma * (double)(float)f1);
     *reinterpret_cast<bf16x2*>(x0 + o) = xo;
   }
 }
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const bf16_t* __restrict
                                                         const void* __restrict__ timestep, int t_is_i64,
                                                         const float* __restrict__ sigmas, const float* __restrict__ timesteps,
                                                         int n_table, bf16_t* __restrict__ out, long inner) {
+#pragma clang fp contract(off)  // torch evaluates (1-s)*x0, s*eps and their sum as separate fp32 ops
   const long base = (long)blockIdx.y * inner;
   const float sigma = (float)block_sigma_lookup(read_timestep(timestep, t_is_i64, blockIdx.y), sigmas, timesteps, n_table);
   const float om = 1.0f - sigma;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const bf16_t* __restrict
     const bf16x8 e = *reinterpret_cast<const bf16x8*>(eps + base + i * 8);
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)__fadd_rn(__fmul_rn(om, (float)a[j]), __fmul_rn(sigma, (float)e[j]));  // no FMA contraction: torch evaluates the two products and the sum separately
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(om * (float)a[j] + sigma * (float)e[j]);
     *reinterpret_cast<bf16x8*>(out + base + i * 8) = o;
   }
 }

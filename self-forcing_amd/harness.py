@@ -16,6 +16,7 @@ class SyntheticTextEncoder:
 
     def __init__(self, text_len: int = 512, text_dim: int = 4096, device="cuda", dtype=torch.bfloat16):
         self.text_len, self.text_dim, self.device, self.dtype = text_len, text_dim, device, dtype
+        self._cache = {}
 
     def embed_one(self, prompt: str) -> torch.Tensor:
         seed = zlib.crc32(prompt.encode("utf-8"))
@@ -26,8 +27,11 @@ class SyntheticTextEncoder:
         return e
 
     def __call__(self, text_prompts: List[str]) -> dict:
-        pe = torch.stack([self.embed_one(p) for p in text_prompts]).to(self.dtype)
-        return {"prompt_embeds": pe.to(self.device)}
+        key = tuple(text_prompts)
+        if key not in self._cache:  # embeddings stay resident on the device, like a real encoder's output
+            pe = torch.stack([self.embed_one(p) for p in text_prompts]).to(self.dtype)
+            self._cache[key] = pe.to(self.device)
+        return {"prompt_embeds": self._cache[key]}
 
 
 class FixedTextEncoder:
