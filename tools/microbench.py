@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks at the S1 shapes (for rocprofv3 --pmc passes and A/B timing):
+self-attention N=4680 x Lk, and the four GEMM shapes of one DiT block."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from self_forcing_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="attn,gemm")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--n", type=int, default=4680)
+    ap.add_argument("--lk", default="4680,18720,32760")
+    ap.add_argument("--heads", type=int, default=12)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    C = a.heads * 128
+    if "attn" in a.what:
+        q = torch.randn(1, a.n, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+        for lk in [int(x) for x in a.lk.split(",")]:
+            k = torch.randn(1, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+            v = torch.randn(1, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+            ms = timeit(lambda: ops.attention(q, k, v), a.iters)
+            fl = 4.0 * C * a.n * lk
+            print(f"attention N={a.n} Lk={lk} H={a.heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    if "gemm" in a.what:
+        for (N, K, epi) in [(3 * C, C, "bias"), (C, C, "resid"), (8960 if C == 1536 else 13824, C, "gelu"),
+                            (C, 8960 if C == 1536 else 13824, "resid")]:
+            x = torch.randn(a.n, K, generator=g).to(torch.bfloat16).to(dev)
+            w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+            b = torch.zeros(N, dtype=torch.bfloat16, device=dev)
+            r = torch.zeros(a.n, N, dtype=torch.bfloat16, device=dev)
+            o = torch.empty(a.n, N, dtype=torch.bfloat16, device=dev)
+            kw = {"resid": r} if epi == "resid" else {}
+            ms = timeit(lambda: ops.gemm(x, w, b, epilogue=epi, out=o, **kw), a.iters)
+            print(f"gemm M={a.n} N={N} K={K} {epi:6s}: {ms * 1e3:8.1f} us  {2.0 * a.n * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
