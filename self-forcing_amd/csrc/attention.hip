@@ -20,6 +20,7 @@
 // LDS image of a [64 keys][128 d] bf16 tile: 256-byte rows, the 16-byte chunk `ch` of row `row`
 // lives at chunk ch ^ (((row&3)<<2) | ((row>>2)&3)); this one image serves the row reads
 // (ds_read_b128, K) and the transposed reads (V) without bank conflicts.
+#include <type_traits>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
 
@@ -93,15 +94,24 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) st_lds[i] = lds_off(st_row + 16 * i, st_ch);
 
+  // K/V tiles come in through buffer loads: the per-lane byte offset is loop invariant, the tile
+  // advances through the scalar offset, and rows past Lk fall outside the descriptor's range and
+  // read as zero (no clamping, no per-tile address arithmetic).  The range of one (batch, head)
+  // slab is (Lk-1) * stride + 128 elements < 2^31 bytes (checked on the host).
+  const unsigned kv_bytes = (unsigned)(((long)(p.Lk - 1) * p.kv_stride + HD) * 2);
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, kv_bytes, 0x00020000);
+  unsigned st_goff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) st_goff[i] = (unsigned)(((long)(st_row + 16 * i) * p.kv_stride + st_ch * 8) * 2);
+  const unsigned tile_bytes = (unsigned)((long)KT * p.kv_stride * 2);
   u32x4 kreg[4], vreg[4];
   auto load_tile = [&](int t) {
-    const int key0 = t * KT;
+    const unsigned soff = (unsigned)t * tile_bytes;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int key = min(key0 + st_row + 16 * i, p.Lk - 1);
-      const long off = (long)key * p.kv_stride + st_ch * 8;
-      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + off);
-      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + off);
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, st_goff[i], soff, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, st_goff[i], soff, 0);
     }
   };
   auto write_tile = [&](int buf) {
@@ -114,16 +124,30 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
     }
   };
 
-  // ---- fragment read offsets
-  // K rows: lane reads row (kb*32 + r32), chunk 2 s + hh
-  int k_off[2][8];
+  // ---- fragment read offsets: per-lane bases, everything else is a compile-time immediate.
+  // K rows: row = kb*32 + r32, chunk (2s + hh) ^ swz(r32) = (2s) ^ x with x = hh ^ swz(r32).
+  int k_addr[8];
+  {
+    const int x = hh ^ (((r32 & 3) << 2) | ((r32 >> 2) & 3));
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+    for (int s = 0; s < 8; ++s) k_addr[s] = 256 * r32 + 16 * ((2 * s) ^ x);
+  }
+  // V transposed reads (ds_read_b64_tr_b16): 16-lane group g covers d = db*32 + 16 (g&1) .. +15 and
+  // keys r0 .. r0+3 with r0 = 16 ks + 4 hh (elements 0-3) or + 8 (elements 4-7); lane 4q+p of the
+  // group addresses row r0+q, columns 4p..4p+3.  With y = 2 (g&1) + (p>>1):
+  //   lo: 256 (4hh + q)     + 16 (4 (db ^ q) + (y ^ hh))       + 8 (p&1) + 4096 ks
+  //   hi: 256 (8 + 4hh + q) + 16 (4 (db ^ q) + (y ^ (hh + 2))) + 8 (p&1) + 4096 ks
+  int v_lo[4], v_hi[4];
+  {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int tq = i16 >> 2, tp = i16 & 3;
+    const int y = 2 * (g & 1) + (tp >> 1);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) k_off[kb][s] = lds_off(kb * 32 + r32, 2 * s + hh);
-  // V transposed reads: 16-lane group g: d base = db*32 + 16 (g&1); key rows r0 = 16 ks + 4 hh (+8)
-  const int g = lane >> 4, i16 = lane & 15;
-  const int tq = i16 >> 2, tp = i16 & 3;
+    for (int db = 0; db < 4; ++db) {
+      v_lo[db] = 256 * (4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ hh)) + 8 * (tp & 1);
+      v_hi[db] = 256 * (8 + 4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ (hh + 2))) + 8 * (tp & 1);
+    }
+  }
 
   f32x16 o_acc[4];
 #pragma unroll
@@ -138,27 +162,42 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
   write_tile(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  auto process_tile = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int cur = t & 1;
-    if (t + 1 < ntiles) load_tile(t + 1);
     const char* kb_lds = smem + cur * (2 * TILE_B);
     const char* vb_lds = kb_lds + TILE_B;
 
-    // ---- S^T = K . Q^T
+    // ---- S^T = K . Q^T : all 16 K fragments are requested up front, the MFMA chains drain them
+    bf16x8 kf[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) kf[kb][s] = *reinterpret_cast<const bf16x8*>(kb_lds + kb * 8192 + k_addr[s]);
+    // prefetch the next K/V tile into registers (the last iteration re-loads its own tile: harmless,
+    // and keeping the loop body branch-free keeps the compiler's s_waitcnt bookkeeping exact)
+    load_tile(min(t + 1, ntiles - 1));
     f32x16 st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_lds + k_off[kb][s]);
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
-      }
+      for (int s = 0; s < 8; ++s) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][s], qf[s], st[kb], 0, 0, 0);
     }
 
+    // ---- first half of the V^T fragments: requested now, they land while the softmax runs
+    bf16x4 vlo[2][4], vhi[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        vlo[ks][db] = lds_tr_read(vb_lds + ks * 4096 + v_lo[db]);
+        vhi[ks][db] = lds_tr_read(vb_lds + ks * 4096 + v_hi[db]);
+      }
+
     // ---- mask the tail keys of the last tile
-    if (t == ntiles - 1 && (p.Lk & (KT - 1)) != 0) {
+    if (MASK) {
       const int key0 = t * KT + 4 * hh;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -169,16 +208,26 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
         }
     }
 
-    // ---- online softmax (per query = per lane pair)
-    float mx = st[0][0];
+    // ---- online softmax (per query = per lane pair l, l+32)
+    float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(st[0][r], st[1][r]));
+    {
+      const unsigned mi = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (__any(mx > m_run)) {  // wave-uniform: some row's running max grew -> rescale what is at the old max
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+    }
+    const float mc = m_run * c;
     float lsum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -188,12 +237,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
         st[kb][r] = pv;
         lsum += pv;
       }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+    l_run += lsum;
 
     // ---- P^T fragments (B operand): k-step ks <- registers 8 (ks&1) .. +7 of st[ks>>1]
     bf16x8 pf[4];
@@ -203,24 +247,35 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
       for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16_t)st[ks >> 1][8 * (ks & 1) + j];
 
     // ---- O^T += V^T . P^T
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int r0 = 16 * ks + 4 * hh;
+    auto pv_step = [&](int ks, const bf16x4 (&lo)[4], const bf16x4 (&hi)[4]) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const int c0 = 4 * db + 2 * (g & 1);
-        const bf16x4 lo = lds_tr_read(vb_lds + lds_off(r0 + tq, c0 + (tp >> 1)) + 8 * (tp & 1));
-        const bf16x4 hi = lds_tr_read(vb_lds + lds_off(r0 + 8 + tq, c0 + (tp >> 1)) + 8 * (tp & 1));
         bf16x8 vf;
-        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+        vf[0] = lo[db][0]; vf[1] = lo[db][1]; vf[2] = lo[db][2]; vf[3] = lo[db][3];
+        vf[4] = hi[db][0]; vf[5] = hi[db][1]; vf[6] = hi[db][2]; vf[7] = hi[db][3];
         o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o_acc[db], 0, 0, 0);
       }
-    }
+    };
+    bf16x4 wlo[2][4], whi[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        wlo[ks][db] = lds_tr_read(vb_lds + (ks + 2) * 4096 + v_lo[db]);
+        whi[ks][db] = lds_tr_read(vb_lds + (ks + 2) * 4096 + v_hi[db]);
+      }
+    pv_step(0, vlo[0], vhi[0]);
+    pv_step(1, vlo[1], vhi[1]);
+    pv_step(2, wlo[0], whi[0]);
+    pv_step(3, wlo[1], whi[1]);
 
-    if (t + 1 < ntiles) write_tile(cur ^ 1);
+    write_tile(cur ^ 1);
     __syncthreads();
-  }
+  };
+  const bool tail = (p.Lk & (KT - 1)) != 0;
+  const int nfull = tail ? ntiles - 1 : ntiles;
+  for (int t = 0; t < nfull; ++t) process_tile(t, std::false_type{});
+  if (tail) process_tile(ntiles - 1, std::true_type{});
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -250,6 +305,7 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   SF_CHECK(q_bstride % 8 == 0 && kv_bstride % 8 == 0 && o_bstride % 4 == 0, "sf_attention: batch strides must keep alignment");
   SF_CHECK(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),
            "sf_attention: misaligned tensor");
+  SF_CHECK(((long)(Lk - 1) * kv_stride + 128) * 2 < (1L << 31), "sf_attention: one (batch, head) K/V slab must span < 2 GiB");
   AttP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)out;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
