@@ -1,0 +1,226 @@
+"""CPU tests of the host logic: cache index arithmetic, scheduler tables, prompt sharding, weight
+handling, the C-ABI library's symbols, and the N>1 bench protocol over gloo (world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import self_forcing_amd as sfa
+from self_forcing_amd.kvcache import plan_cache_update
+from self_forcing_amd.sharding import shard_indices, shard
+from oracle import wan_oracle as wo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------------------- cache plan
+def test_plan_matches_oracle_on_random_call_sequences():
+    """plan_cache_update (product) == kv_cache_plan (oracle restatement of causal_model.py:202-236)
+    over random chunk sequences incl. re-runs and rolling-window eviction."""
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        fs = int(rng.integers(1, 40))
+        las = int(rng.choice([-1, 2, 3, 5, 8]))
+        sink = int(rng.integers(0, max(1, las))) if las != -1 else 0
+        nf = int(rng.integers(1, 4))
+        frames = int(rng.integers(nf, 12))
+        cap = (las if las != -1 else frames + nf) * fs
+        window = cap if las == -1 else las * fs
+        if las != -1 and (nf > las - sink or nf + sink > las):
+            continue
+        le = ge = 0
+        start = 0
+        for _ in range(frames // nf):
+            for rerun in range(int(rng.integers(1, 4))):
+                n = nf * fs
+                ev, keep, nle, ws, as_ = wo.kv_cache_plan(le, ge, start * fs, n, cap, las, sink * fs, window)
+                p = plan_cache_update(le, ge, start * fs, n, cap, las, sink * fs, window)
+                assert (p.evict, p.keep, p.local_end, p.write_start, p.attn_start) == (ev, keep, nle, ws, as_)
+                assert p.global_end == start * fs + n
+                le, ge = p.local_end, p.global_end
+            start += nf
+
+
+def test_plan_rolling_window_golden_indices():
+    """local_attn_size=3, sink=1, one-frame chunks, 24 tokens/frame: the index trace the reference
+    produced (tests/golden/modules_reduced.npz: sa_local_end / sa_global_end)."""
+    mods = np.load(os.path.join(GOLD, "modules_reduced.npz"))
+    fs, le, ge = 24, 0, 0
+    for st, want_le, want_ge in zip(mods["sa_starts"], mods["sa_local_end"], mods["sa_global_end"]):
+        p = plan_cache_update(le, ge, int(st) * fs, fs, 3 * fs, 3, 1 * fs, 3 * fs)
+        le, ge = p.local_end, p.global_end
+        assert (le, ge) == (int(want_le), int(want_ge))
+
+
+def test_plan_overflow_in_global_mode_raises():
+    with pytest.raises(RuntimeError, match="overflow"):
+        plan_cache_update(local_end=48, global_end=48, current_start=48, num_new=24, capacity=48,
+                          local_attn_size=-1, sink_tokens=0, max_attention_size=48)
+
+
+def test_plan_rerun_overwrites_in_place():
+    p1 = plan_cache_update(0, 0, 0, 10, 100, -1, 0, 100)
+    p2 = plan_cache_update(p1.local_end, p1.global_end, 0, 10, 100, -1, 0, 100)
+    assert (p1.write_start, p1.local_end) == (p2.write_start, p2.local_end) == (0, 10)
+
+
+# -------------------------------------------------------------------------------- scheduler
+@pytest.mark.parametrize("shift", [5.0, 8.0])
+def test_scheduler_tables_match_reference_golden(shift):
+    g = np.load(os.path.join(GOLD, "ops.npz"))
+    s = sfa.FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
+    s.set_timesteps(1000, training=True)
+    tag = str(int(shift))
+    assert np.array_equal(s.sigmas.numpy(), g[f"sched{tag}_sigmas"])
+    assert np.array_equal(s.timesteps.numpy(), g[f"sched{tag}_timesteps"])
+    table = torch.cat((s.timesteps, torch.tensor([0], dtype=torch.float32)))
+    warped = table[1000 - torch.tensor([1000, 750, 500, 250])]
+    assert np.array_equal(warped.numpy(), g[f"sched{tag}_warped"])
+
+
+# --------------------------------------------------------------------------------- sharding
+def test_shard_indices_distributed_sampler_semantics():
+    """DistributedSampler(shuffle=False, drop_last=True): first W*floor(P/W) prompts, rank::W."""
+    from torch.utils.data import DistributedSampler
+    for P, W in [(64, 8), (10, 4), (7, 2), (3, 4), (1003, 8)]:
+        data = list(range(P))
+        used = set()
+        for r in range(W):
+            ref = list(DistributedSampler(data, num_replicas=W, rank=r, shuffle=False, drop_last=True))
+            assert shard_indices(P, r, W) == ref
+            used.update(ref)
+        assert used == set(range(W * (P // W)))
+    assert shard(["a", "b", "c", "d", "e"], 1, 2) == ["b", "d"]
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
+
+
+# ---------------------------------------------------------------------------------- weights
+def test_synth_weights_deterministic_and_complete():
+    a = sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0)
+    b = sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0)
+    c = sfa.synth_state_dict(sfa.WAN_REDUCED, seed=1)
+    assert set(a) == set(sfa.param_shapes(sfa.WAN_REDUCED))
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["head.head.weight"], c["head.head.weight"])
+    assert a["head.head.weight"].abs().sum() > 0          # the reference zero-inits it (vacuous output)
+    n13 = sum(int(np.prod(s)) for s in sfa.param_shapes(sfa.WAN_1_3B).values())
+    assert abs(n13 - 1.419e9) < 2e6                        # 1.419 B without pose_proj
+
+
+def test_merge_lora_and_prefix_strip():
+    g = torch.Generator().manual_seed(0)
+    W, A, B = torch.randn(8, 6, generator=g), torch.randn(2, 6, generator=g), torch.randn(8, 2, generator=g)
+    sd = {"model.blocks.0.self_attn.q.base.weight": W, "model.blocks.0.self_attn.q.base.bias": torch.zeros(8),
+          "model.blocks.0.self_attn.q.lora_A.weight": A, "model.blocks.0.self_attn.q.lora_B.weight": B,
+          "model.head.head.weight": torch.ones(4, 6)}
+    out = sfa.merge_lora(sfa.strip_prefix(sd), alpha=4.0, rank=2)
+    assert set(out) == {"blocks.0.self_attn.q.weight", "blocks.0.self_attn.q.bias", "head.head.weight"}
+    x = torch.randn(3, 6, generator=g)
+    ref = x @ W.t() + (x @ A.t() @ B.t()) * (4.0 / 2)      # utils/lora.py:47-50
+    assert torch.allclose(x @ out["blocks.0.self_attn.q.weight"].t(), ref, atol=1e-5)
+
+
+# -------------------------------------------------------------------------------- the C-ABI
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The built C-ABI library loads and exports exactly what include/sf_hip.h declares (no
+    compute call: there is no GPU here)."""
+    lib_path = sfa._lib.LIB_PATH
+    if not os.path.exists(lib_path):
+        sfa._lib.build()
+    handle = ctypes.CDLL(lib_path)
+    declared = _header_symbols()
+    assert declared, "no symbols parsed from the header"
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in sf_hip.h but not exported"
+    assert set(declared) == set(sfa._lib.SIGNATURES), "ctypes SIGNATURES out of sync with the header"
+    handle.sf_abi_version.restype = ctypes.c_int
+    assert handle.sf_abi_version() == sfa._lib.ABI_VERSION
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
+    lib = sfa._lib.lib()
+    assert lib.sf_gemm_bf16(None, None) != 0
+    assert b"null" in lib.sf_last_error()
+    g = sfa._lib.GemmArgs()
+    g.M, g.N, g.K = 4, 8, 100
+    assert lib.sf_gemm_bf16(g, None) != 0 and b"K=100" in lib.sf_last_error()
+    assert lib.sf_attention(None, None, None, None, 1, 1, 1, 1, 128, 128, 128, 128, 128, 128, None) != 0
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU fallback: the op wrappers reject host tensors instead of computing something."""
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="CUDA"):
+        sfa.ops.gemm(x, x)
+    with pytest.raises(ValueError, match="CUDA"):
+        sfa.ops.attention(torch.zeros(1, 4, 1, 128, dtype=torch.bfloat16), torch.zeros(1, 4, 1, 128, dtype=torch.bfloat16),
+                          torch.zeros(1, 4, 1, 128, dtype=torch.bfloat16))
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(sfa._lib, "_lib", None)
+    monkeypatch.setattr(sfa._lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(sfa._lib.SfHipError, match="no CPU/eager fallback"):
+        sfa._lib.lib()
+
+
+# ------------------------------------------------------------ N > 1 protocol over gloo (CPU)
+_WORKER = r'''
+import os, sys, json, time
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SF_ROOT"])
+from self_forcing_amd.sharding import shard_indices
+import self_forcing_amd as sfa
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+# identical replicas: same seeded weights everywhere, proven with a checksum MIN/MAX all-reduce
+sd = sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0)
+cs = torch.stack([v.double().sum() for v in sd.values()]).sum().reshape(1)
+lo, hi = cs.clone(), cs.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert lo.item() == hi.item()
+steps = 3
+idx = shard_indices(steps * world, rank, world)
+dist.barrier()
+t0 = time.perf_counter()
+time.sleep(0.05 * (rank + 1))          # rank-dependent "work": the slowest rank sets the time
+dist.barrier()
+el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+dist.all_reduce(el, op=dist.ReduceOp.MAX)
+seen = [None] * world
+dist.all_gather_object(seen, idx)
+if rank == 0:
+    print(json.dumps({"elapsed": el.item(), "idx": seen, "frames": world * steps * 81}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_protocol(tmp_path):
+    """World size 2 on CPU: replica checksum, rank::W prompt assignment with no overlap, barrier +
+    max-over-ranks timing -- the protocol bench.py runs over RCCL."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, SF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    import json
+    out = json.loads(line)
+    assert out["idx"] == [[0, 2, 4], [1, 3, 5]]
+    assert out["elapsed"] >= 0.1 - 1e-3          # max over ranks: rank 1 slept 0.1 s
+    assert out["frames"] == 2 * 3 * 81
