@@ -20,6 +20,7 @@
 // LDS image of a [64 keys][128 d] bf16 tile: 256-byte rows, the 16-byte chunk `ch` of row `row`
 // lives at chunk ch ^ (((row&3)<<2) | ((row>>2)&3)); this one image serves the row reads
 // (ds_read_b128, K) and the transposed reads (V) without bank conflicts.
+#include <cstdlib>
 #include <type_traits>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
@@ -42,6 +43,7 @@ struct AttP {
   long q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride;
   int q_tiles;
   float scale_log2;  // (1/sqrt(D)) * log2(e)
+  int prio_mode;     // experiment knob: 0 none, 1 QK+softmax segment high, 2 PV segment high
 };
 
 __device__ __forceinline__ int lds_off(int row, int ch) {
@@ -294,6 +296,295 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// 8-wave structure (used when it fills the chip): ONE workgroup per CU = 256 query rows of one
+// (batch, head).  Waves 0-3 (half A) and 4-7 (half B) share the four SIMDs pairwise (w, w+4).  The
+// per-tile work of a wave is cut into a MATRIX segment and a VECTOR segment,
+//     matrix(t):  O^T += V^T(t-1) . P^T(t-1)   then   S^T(t) = K(t) . Q^T      (32 MFMAs, ~0 VALU)
+//     vector(t):  online softmax of S^T(t) -> P^T(t) in bf16                   (~130 VALU, 0 MFMA)
+// and the halves run them in anti-phase, one s_barrier per global step g:
+//     g = 2t   : A matrix(t)   | B vector(t-1)
+//     g = 2t+1 : A vector(t)   | B matrix(t)
+// so every SIMD always has one wave feeding the matrix pipe and its partner issuing VALU
+// (an MFMA blocks the SIMD's vector issue for only 8 of its 32 cycles).  Two independent 4-wave
+// workgroups per CU drift into lockstep instead (measured: 45 % MFMA-busy, 35 % co-execution), and
+// pairing "QK^T + softmax" with "PV" does not help either: the two MFMA streams share the pipe,
+// finish together and leave the softmax alone.
+// LDS: K and V double-buffered separately (64 KiB).  K(t) and V(t-1) are read in steps 2t (A) and
+// 2t+1 (B); K(t+1) and V(t) are fetched to registers in step 2t and written in step 2t+1 into the
+// buffers of K(t-1) / V(t-2), both dead since step 2t-1.
+constexpr int QT8 = 256;
+constexpr int ATT8_THREADS = 512;
+constexpr int ATT8_LDS = 4 * TILE_B;  // K0 K1 V0 V1 = 64 KiB
+
+template <int KIND>
+__global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2;  // 0 = A, 1 = B
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = wg / p.q_tiles, qt = wg - bh * p.q_tiles;
+  const int b = bh / p.H, head = bh - b * p.H;
+
+  const bf16_t* qbase = p.q + (long)b * p.q_bstride + head * HD;
+  const bf16_t* kbase = p.k + (long)b * p.kv_bstride + head * HD;
+  const bf16_t* vbase = p.v + (long)b * p.kv_bstride + head * HD;
+  bf16_t* obase = p.o + (long)b * p.o_bstride + head * HD;
+
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int qrow = qt * QT8 + wave * 32 + r32;
+  const int qrow_c = min(qrow, p.Lq - 1);
+
+  bf16x8 qf[8];
+  {
+    const bf16_t* qp = qbase + (long)qrow_c * p.q_stride + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+  }
+
+  // staging: 512 threads; a thread moves chunk (row = tid>>4 (+32), ch = tid&15) of a K and a V tile
+  const int st_row = tid >> 4, st_ch = tid & 15;
+  int st_lds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) st_lds[i] = lds_off(st_row + 32 * i, st_ch);
+  const unsigned kv_bytes = (unsigned)(((long)(p.Lk - 1) * p.kv_stride + HD) * 2);
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, kv_bytes, 0x00020000);
+  unsigned st_goff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) st_goff[i] = (unsigned)(((long)(st_row + 32 * i) * p.kv_stride + st_ch * 8) * 2);
+  const unsigned tile_bytes = (unsigned)((long)KT * p.kv_stride * 2);
+  u32x4 kreg[2], vreg[2];
+  auto load_k = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, st_goff[i], (unsigned)t * tile_bytes, 0);
+  };
+  auto load_v = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, st_goff[i], (unsigned)t * tile_bytes, 0);
+  };
+  auto write_k = [&](int t) {
+    char* kb = smem + (t & 1) * TILE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(kb + st_lds[i]) = kreg[i];
+  };
+  auto write_v = [&](int t) {
+    char* vb = smem + (2 + (t & 1)) * TILE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(vb + st_lds[i]) = vreg[i];
+  };
+
+  int k_addr[8];
+  {
+    const int x = hh ^ (((r32 & 3) << 2) | ((r32 >> 2) & 3));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) k_addr[s] = 256 * r32 + 16 * ((2 * s) ^ x);
+  }
+  int v_lo[4], v_hi[4];
+  {
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int tq = i16 >> 2, tp = i16 & 3;
+    const int y = 2 * (g16 & 1) + (tp >> 1);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      v_lo[db] = 256 * (4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ hh)) + 8 * (tp & 1);
+      v_hi[db] = 256 * (8 + 4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ (hh + 2))) + 8 * (tp & 1);
+    }
+  }
+
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[d][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2;
+  bf16x8 pf[4];
+  f32x16 st[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16_t)0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  const bool tail = (p.Lk & (KT - 1)) != 0;
+
+  // ---- matrix segment
+  auto seg_pv = [&](int t) {   // O^T += V^T(t) . P^T
+    const char* vb_lds = smem + (2 + (t & 1)) * TILE_B;
+    bf16x4 vlo[4][4], vhi[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        vlo[ks][db] = lds_tr_read(vb_lds + ks * 4096 + v_lo[db]);
+        vhi[ks][db] = lds_tr_read(vb_lds + ks * 4096 + v_hi[db]);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        bf16x8 vf;
+        vf[0] = vlo[ks][db][0]; vf[1] = vlo[ks][db][1]; vf[2] = vlo[ks][db][2]; vf[3] = vlo[ks][db][3];
+        vf[4] = vhi[ks][db][0]; vf[5] = vhi[ks][db][1]; vf[6] = vhi[ks][db][2]; vf[7] = vhi[ks][db][3];
+        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o_acc[db], 0, 0, 0);
+      }
+    // pin the issue order (hipcc otherwise sinks every read to just before its MFMA and each MFMA
+    // pays an LDS round trip): 8 transposed reads ahead, then 1 MFMA : 2 reads, then the last MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  };
+  auto seg_qk = [&](int t) {   // S^T(t) = K(t) . Q^T
+    const char* kb_lds = smem + (t & 1) * TILE_B;
+    bf16x8 kf[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) kf[kb][s] = *reinterpret_cast<const bf16x8*>(kb_lds + kb * 8192 + k_addr[s]);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][s], qf[s], st[kb], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // 6 K fragments ahead, then 1 MFMA : 1 read
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+  };
+  // ---- vector segment: online softmax of st -> pf
+  auto seg_softmax = [&](int t) {
+    if (tail && t == ntiles - 1) {
+      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch, not 32 selects per tile
+      const int key0 = t * KT + 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= p.Lk) st[kb][r] = -1e30f;
+        }
+    }
+    float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(st[0][r], st[1][r]));
+    {
+      const unsigned mi = __float_as_uint(mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mi, mi, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (__any(mx > m_run)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[d][r] *= alpha;
+    }
+    const float mc = m_run * c;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(st[kb][r] * c - mc);
+        pf[2 * kb + (r >> 3)][r & 7] = (bf16_t)pv;   // k-step ks = 2 kb + (r>>3), element r & 7
+        lsum += pv;
+      }
+    l_run += lsum;
+  };
+
+  load_k(0);
+  write_k(0);
+  __syncthreads();
+
+  // Global steps g = 0 .. 2 ntiles + 1, one barrier after each but the last.  Every thread fetches
+  // K(tt+1), V(tt) in even steps g = 2 tt and publishes them in the following odd step.  The two
+  // halves run the same segments one step apart; written out per half so that every register's
+  // live range is static (st: matrix -> vector of the same tile; pf: vector -> next matrix).
+  // Raw s_barrier + an LDS-only wait: __syncthreads() would also drain vmcnt(0), i.e. stall every
+  // step on the K/V prefetch issued a moment earlier (the loads are consumed a whole step later).
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto fetch = [&](int tt) {
+    if (tt + 1 < ntiles) load_k(tt + 1);
+    if (tt < ntiles) load_v(tt);
+  };
+  auto publish = [&](int tt) {
+    if (tt + 1 < ntiles) write_k(tt + 1);
+    if (tt < ntiles) write_v(tt);
+  };
+  if (half == 0) {
+    for (int t = 0; t < ntiles; ++t) {
+      fetch(t);                       // g = 2t
+      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(2);
+      if (t >= 1) seg_pv(t - 1);
+      seg_qk(t);
+      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(0);
+      step_barrier();
+      seg_softmax(t);                 // g = 2t + 1
+      publish(t);
+      step_barrier();
+    }
+    seg_pv(ntiles - 1);               // g = 2 ntiles
+    step_barrier();
+  } else {
+    fetch(0);                         // g = 0
+    step_barrier();
+    for (int t = 0; t < ntiles; ++t) {
+      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(2);
+      if (t >= 1) seg_pv(t - 1);      // g = 2t + 1
+      seg_qk(t);
+      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(0);
+      publish(t);
+      step_barrier();
+      fetch(t + 1);                   // g = 2t + 2
+      seg_softmax(t);
+      step_barrier();
+    }
+    seg_pv(ntiles - 1);               // g = 2 ntiles + 1
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qrow < p.Lq) {
+    bf16_t* op = obase + (long)qrow * p.o_stride + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (bf16_t)(o_acc[db][4 * rg + j] * inv);
+        *reinterpret_cast<bf16x4*>(op + db * 32 + rg * 8) = w;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
@@ -313,6 +604,19 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   p.o_stride = o_stride; p.o_bstride = o_bstride;
   p.q_tiles = (Lq + QT - 1) / QT;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
+  p.prio_mode = getenv("SF_ATTN_PRIO") ? atoi(getenv("SF_ATTN_PRIO")) : 1;
+  // 256-row / 8-wave structure when it fills most of the chip's 256 CUs in whole rounds, else
+  // 128-row / 4-wave workgroups (two per CU)
+  const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
+  if ((nwg8 >= 192 && !getenv("SF_ATTN_W4")) || getenv("SF_ATTN_W8")) {   // env switches: A/B timing and tests only
+    p.q_tiles = (Lq + QT8 - 1) / QT8;
+    if (Lk > 1024)
+      hipLaunchKernelGGL(attention_w8_kernel<0>, dim3((unsigned)nwg8), dim3(ATT8_THREADS), ATT8_LDS, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL(attention_w8_kernel<1>, dim3((unsigned)nwg8), dim3(ATT8_THREADS), ATT8_LDS, (hipStream_t)stream, p);
+    SF_HIP_LAUNCH_CHECK("sf_attention");
+    return 0;
+  }
   const long nwg = (long)p.q_tiles * H * B;
   SF_CHECK(nwg < (1L << 30), "sf_attention: grid too large");
   if (Lk > 1024)

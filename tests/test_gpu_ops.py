@@ -97,6 +97,30 @@ def test_attention(B, H, Lq, Lk):
     assert rel(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 12, 4200, 300), (2, 8, 3100, 130), (1, 12, 4680, 1561), (1, 16, 3073, 64)])
+def test_attention_w8_structure(B, H, Lq, Lk):
+    """Shapes that fill the chip dispatch the 8-wave staggered kernel (256 query rows / workgroup)."""
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g), bf((B, Lk, H, 128), g)
+    ref = wo.sdpa(q.float(), k.float(), v.float())
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert rel(out, ref) < 6e-3
+
+
+@pytest.mark.parametrize("force", ["SF_ATTN_W8", "SF_ATTN_W4"])
+def test_attention_both_structures_small_and_spiky(force, monkeypatch):
+    """Both kernels on the same ragged inputs incl. a late max spike (rescale branch) and Lk = 1."""
+    monkeypatch.setenv(force, "1")
+    g = torch.Generator().manual_seed(5)
+    for (B, H, Lq, Lk) in [(1, 2, 300, 448), (2, 1, 33, 65), (1, 3, 257, 1), (1, 1, 512, 129)]:
+        q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g, 0.3), bf((B, Lk, H, 128), g)
+        if Lk > 400:
+            k[0, 400, 0] = (q[0, 5, 0].float() * 3).to(torch.bfloat16)
+        ref = wo.sdpa(q.float(), k.float(), v.float())
+        out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+        assert rel(out, ref) < 6e-3, (B, H, Lq, Lk)
+
+
 def test_attention_online_softmax_rescale_branch():
     """Force the running max to jump late: one key far along the sequence dominates one query
     (cdna guide rule 26: a rescale branch needs an input that takes it)."""
