@@ -3,7 +3,7 @@
 // Replaces nn.Linear (+ the elementwise ops after it) on the reference's hot path
 // (wan/modules/causal_model.py:112-114, :240, :277-279, :320, :331, :366; model.py:172-193).
 //
-// Structure (v1): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
+// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave,
 // 4x4 MFMA 16x16x32 bf16 tiles), BK = 64, A and W tiles staged HBM -> LDS by LDS-DMA
 // (global_load_lds_dwordx4) into two buffers so that tile k+1 is in flight while tile k feeds the
 // matrix cores.  Both operands are K-contiguous (activations [M,K], nn.Linear weights [N,K]), so
@@ -13,6 +13,7 @@
 // bank-conflict free.  The MFMA is issued as D = W_frag x X_frag (operands swapped) so that each
 // lane ends up with 4 CONSECUTIVE output columns of one row: 8-byte bf16x4 stores/loads in the
 // epilogue instead of 2-byte scattered ones.
+#include <cstdlib>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
 
@@ -45,6 +46,51 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Epilogue shared by both structures: the lane holds out[m][n .. n+3] for each (mt, nt) of its
+// wave's 64 x 64 sub-tile; m = mrow + 16 mt, n = ncol + 16 nt.
+template <int EPI, int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int mrow, int ncol) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mrow + mt * 16;
+    if (m >= p.M) continue;
+    const bf16_t* e0row = nullptr;
+    if (EPI == SF_EPI_BIAS_GATE_RESID) e0row = p.gate_e0 + (long)(m / p.rows_per_group) * p.gate_group_stride;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = ncol + nt * 16;
+      if (n >= p.N) continue;
+      float y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j];
+      if (p.bias) {
+        const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] += (float)b[j];
+      }
+      if (EPI == SF_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+      }
+      if (EPI == SF_EPI_BIAS_GATE_RESID) {
+        const bf16x4 gm = *reinterpret_cast<const bf16x4*>(p.gate_mod + n);
+        const bf16x4 ge = *reinterpret_cast<const bf16x4*>(e0row + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] *= (float)(bf16_t)((float)gm[j] + (float)ge[j]);
+      }
+      if (EPI == SF_EPI_BIAS_RESID || EPI == SF_EPI_BIAS_GATE_RESID) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
+      *reinterpret_cast<bf16x4*>(p.out + (long)m * p.ldo + n) = o;
+    }
+  }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,7 +104,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  // Grouped order on top of the XCD remap: consecutive workgroups (which run concurrently on one
+  // XCD and advance through K in step) cover GROUP_M row tiles x a run of column tiles, so both the
+  // A panel and the W tiles they stream are shared in that XCD's L2.  Row-major tile order made
+  // every sweep of a row re-read the whole weight matrix: 1.05 GB fetched for the 1.3B ffn.0 GEMM
+  // (FETCH_SIZE x 2) against 126 MB of operands + output.
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = wg / width, first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * width;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging addresses: wave w issues 4 A pieces + 4 W pieces of 1 KiB (8 rows x 128 B) each
@@ -106,67 +162,46 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
     const int cur = kt & 1;
     if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* buf = smem + cur * STAGE_BYTES;
+    // fragments of both 32-deep sub-steps: the second set is requested while the first set's MFMAs
+    // run (issue order pinned below; left alone, hipcc reads just in time and every group of MFMAs
+    // waits out an LDS round trip)
+    bf16x8 xf0[4], wf0[4], xf1[4], wf1[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int coff = s ? coff1 : coff0;
-      bf16x8 xf[4], wf[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xf[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff);
-        wf[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+      xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff0);
+      wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff0);
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      xf1[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff1);
+      wf1[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     __syncthreads();  // drains the in-flight LDS-DMA (vmcnt(0)) and orders the buffer swap
   }
 
   // ---- epilogue: lane holds out[m][n .. n+3] for (mt, nt)
   const int mrow = m0 + wr * 64 + (lane & 15);
   const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = mrow + mt * 16;
-    if (m >= p.M) continue;
-    const bf16_t* e0row = nullptr;
-    if (EPI == SF_EPI_BIAS_GATE_RESID) e0row = p.gate_e0 + (long)(m / p.rows_per_group) * p.gate_group_stride;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = ncol + nt * 16;
-      if (n >= p.N) continue;
-      float y[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j];
-      if (p.bias) {
-        const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] += (float)b[j];
-      }
-      if (EPI == SF_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
-      }
-      if (EPI == SF_EPI_BIAS_GATE_RESID) {
-        const bf16x4 gm = *reinterpret_cast<const bf16x4*>(p.gate_mod + n);
-        const bf16x4 ge = *reinterpret_cast<const bf16x4*>(e0row + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] *= (float)(bf16_t)((float)gm[j] + (float)ge[j]);
-      }
-      if (EPI == SF_EPI_BIAS_RESID || EPI == SF_EPI_BIAS_GATE_RESID) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
-      *reinterpret_cast<bf16x4*>(p.out + (long)m * p.ldo + n) = o;
-    }
-  }
+  gemm_epilogue<EPI, 4>(p, acc, mrow, ncol);
 }
+
 
 }  // namespace
 
@@ -192,10 +227,10 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
   p.gate_mod = (const bf16_t*)a->gate_mod; p.gate_e0 = (const bf16_t*)a->gate_e0;
   p.gate_group_stride = a->gate_group_stride; p.rows_per_group = a->rows_per_group;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
-  p.tiles_m = (a->M + BM - 1) / BM;
   p.tiles_n = (a->N + BN - 1) / BN;
-  const dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
   hipStream_t s = (hipStream_t)stream;
+  p.tiles_m = (a->M + BM - 1) / BM;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
   switch (a->epilogue) {
     case SF_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS>, grid, block, GEMM_LDS, s, p); break;
     case SF_EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS_GELU>, grid, block, GEMM_LDS, s, p); break;

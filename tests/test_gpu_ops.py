@@ -65,6 +65,31 @@ def test_gemm(M, N, K, epi):
     assert (out.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4680, 1536, 1536, "gate_resid"), (4100, 2048, 128, "gelu"), (300, 192, 192, "bias"),
+                                       (5000, 1664, 640, "resid")])
+def test_gemm_large_ragged(M, N, K, epi):
+    """Full-width problems: ragged M, N not a multiple of the tile, K of 2..24 steps, grouped tile
+    order with a partial last row group."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias, resid = bf((M, K), g), bf((N, K), g, 1.0 / K ** 0.5), bf((N,), g, 0.5), bf((M, N), g)
+    groups = 3 if M % 3 == 0 else 1
+    gate_mod, e0 = bf((N,), g, 0.5), bf((groups, 6, N), g, 0.5)
+    y = a.float() @ w.float().t() + bias.float()
+    kw = {}
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(y, approximate="tanh")
+    elif epi == "resid":
+        ref, kw = resid.float() + y, {"resid": resid.to(DEV)}
+    elif epi == "gate_resid":
+        gate = (gate_mod.float()[None] + e0[:, 5].float()).to(torch.bfloat16).float()
+        ref = resid.float() + y * gate.repeat_interleave(M // groups, dim=0)
+        kw = dict(resid=resid.to(DEV), gate_mod=gate_mod.to(DEV), gate_e0=e0.to(DEV)[:, 5], rows_per_group=M // groups)
+    else:
+        ref = y
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), epilogue=epi, **kw)
+    assert rel(out, ref) < 4e-3
+
+
 def test_gemm_inplace_residual_and_strides():
     g = torch.Generator().manual_seed(3)
     M, N, K = 300, 256, 192
