@@ -159,13 +159,14 @@ def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=21, help="latent frames per rollout")
     ap.add_argument("--model", default="Wan2.1-T2V-1.3B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile", action="store_true", help="print the pipeline's per-chunk event timing")
+    ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -190,7 +191,7 @@ def main():
                            num_frame_per_block=nfpb, context_noise=0)
     gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=shift, is_causal=True, device=dev)
     enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=dev)
-    pipe = sfa.CausalInferencePipeline(args, dev, generator=gen, text_encoder=enc, vae=sfa.IdentityVAE())
+    pool = sfa.RolloutPool(args, dev, gen, lambda: enc, sfa.IdentityVAE, streams=a.streams)
 
     if dist is not None:  # every rank must hold the same replica: compare a checksum over RCCL
         cs = torch.stack([t.float().sum() for t in gen.model._keep[:64]]).sum().reshape(1).double()
@@ -206,23 +207,23 @@ def main():
         enc([p])                                                # embeddings resident in HBM before timing
     torch.manual_seed(0 + rank)                                 # set_seed(seed + rank), inference.py:45
 
-    def one_step(i):
+    def one_step(pipe, i):
         noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
         return pipe.inference(noise, [prompts[i]], return_latents=True, profile=a.profile and rank == 0)[1]
 
-    log(f"model resident ({gen.model.param_bytes() / 1e9:.2f} GB); warmup x{a.warmup}")
-    for i in range(a.warmup):
-        tw = time.perf_counter()
-        one_step(i)
-        torch.cuda.synchronize()
-        log(f"warmup step {i}: {time.perf_counter() - tw:.2f} s")
+    log(f"model resident ({gen.model.param_bytes() / 1e9:.2f} GB); warmup x{a.warmup}, {a.streams} stream(s)")
+    tw = time.perf_counter()
+    # every stream's pipeline must have seen one rollout (cache / workspace allocation) before timing
+    if a.warmup:
+        pool.run_each(lambda pipe: one_step(pipe, 0))
+        pool.run(list(range(min(a.streams, a.warmup), a.warmup)), one_step)
     torch.cuda.synchronize()
+    log(f"warmup: {time.perf_counter() - tw:.2f} s")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.warmup, total):
-        lat = one_step(i)
+    lats = pool.run(list(range(a.warmup, total)), one_step)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -233,6 +234,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+    lat = lats[-1]
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
 
     decoded = DECODED_PER_LATENT(a.frames)
@@ -245,9 +247,10 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"S1: {a.model}-shape random-init weights, latent {a.frames}x16x{LAT_H}x{LAT_W} "
                                f"({decoded} decoded frames), {nfpb} frames/chunk, steps {step_list} warped (shift {shift}) "
-                               f"+ 1 context pass per chunk, batch 1 per GPU, prompts sharded rank::N",
+                               f"+ 1 context pass per chunk, batch 1 per rollout, {a.streams} rollout(s) in flight per GPU "
+                               f"(one HIP stream each, shared weights), prompts sharded rank::N",
                    "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
-                   "parallelism": f"prompt-sharded x{world}"},
+                   "parallelism": f"prompt-sharded x{world}", "streams_per_gpu": a.streams},
         "algorithmic_tflop_per_step": flops / 1e12,
         "achieved_tflops_per_gpu": flops * a.steps / elapsed / 1e12,
         "mfma_frac_end_to_end": flops * a.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,

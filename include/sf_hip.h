@@ -188,6 +188,10 @@ typedef struct sf_forward_args {
   int32_t start_frame;                    /* RoPE time offset = current_start // (h*w) */
   void* evict_scratch;                    /* >= batch * keep * dim * 2 bytes when evict > 0 */
   size_t evict_scratch_bytes;
+  int32_t cache_only;                     /* 1: only the KV-cache update is wanted (the context pass /
+                                             warm-up passes, whose outputs the pipeline discards,
+                                             causal_inference.py:143-168, :227-235): everything after
+                                             the LAST layer's K/V write is skipped, outputs untouched */
   void* flow_out;                         /* [B, F, out_dim, H, W] */
   void* x0_out;                           /* [B, F, out_dim, H, W] */
   void* workspace;

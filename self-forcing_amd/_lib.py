@@ -66,6 +66,7 @@ class ForwardArgs(C.Structure):
         ("write_start", C.c_int32), ("attn_start", C.c_int32), ("attn_end", C.c_int32),
         ("start_frame", C.c_int32),
         ("evict_scratch", C.c_void_p), ("evict_scratch_bytes", C.c_size_t),
+        ("cache_only", C.c_int32),
         ("flow_out", C.c_void_p), ("x0_out", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]

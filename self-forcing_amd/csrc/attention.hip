@@ -43,7 +43,6 @@ struct AttP {
   long q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride;
   int q_tiles;
   float scale_log2;  // (1/sqrt(D)) * log2(e)
-  int prio_mode;     // experiment knob: 0 none, 1 QK+softmax segment high, 2 PV segment high
 };
 
 __device__ __forceinline__ int lds_off(int row, int ch) {
@@ -311,6 +310,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
 // workgroups per CU drift into lockstep instead (measured: 45 % MFMA-busy, 35 % co-execution), and
 // pairing "QK^T + softmax" with "PV" does not help either: the two MFMA streams share the pipe,
 // finish together and leave the softmax alone.
+// (A 64-rows-per-wave variant -- every K/V fragment feeding two MFMAs, 19 instead of 34 LDS bytes
+// per kflop -- was built and measured at 557 TFLOP/s: with 512 registers per wave hipcc parks
+// accumulators in AGPRs and pays hundreds of v_accvgpr moves per tile; that design needs hand-placed
+// assembly and is left for a later round.)
 // LDS: K and V double-buffered separately (64 KiB).  K(t) and V(t-1) are read in steps 2t (A) and
 // 2t+1 (B); K(t+1) and V(t) are fetched to registers in step 2t and written in step 2t+1 into the
 // buffers of K(t-1) / V(t-2), both dead since step 2t-1.
@@ -541,10 +544,8 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
   if (half == 0) {
     for (int t = 0; t < ntiles; ++t) {
       fetch(t);                       // g = 2t
-      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(2);
       if (t >= 1) seg_pv(t - 1);
       seg_qk(t);
-      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(0);
       step_barrier();
       seg_softmax(t);                 // g = 2t + 1
       publish(t);
@@ -556,10 +557,8 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
     fetch(0);                         // g = 0
     step_barrier();
     for (int t = 0; t < ntiles; ++t) {
-      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(2);
       if (t >= 1) seg_pv(t - 1);      // g = 2t + 1
       seg_qk(t);
-      if (p.prio_mode & 1) __builtin_amdgcn_s_setprio(0);
       publish(t);
       step_barrier();
       fetch(t + 1);                   // g = 2t + 2
@@ -585,6 +584,7 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
   }
 }
 
+
 }  // namespace
 
 extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
@@ -604,7 +604,6 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   p.o_stride = o_stride; p.o_bstride = o_bstride;
   p.q_tiles = (Lq + QT - 1) / QT;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
-  p.prio_mode = getenv("SF_ATTN_PRIO") ? atoi(getenv("SF_ATTN_PRIO")) : 1;
   // 256-row / 8-wave structure when it fills most of the chip's 256 CUs in whole rounds, else
   // 128-row / 4-wave workgroups (two per CU)
   const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;

@@ -87,7 +87,8 @@ extern "C" int sf_dit_forward(const sf_model* m, const sf_forward_args* a, void*
   SF_CHECK(F % G == 0, "sf_dit_forward: frames=%d not divisible by timestep groups=%d", F, G);
   const int rpg = L / G;
   SF_CHECK(BG <= 32, "sf_dit_forward: batch*groups=%d exceeds the small-linear limit of 32", BG);
-  SF_CHECK(a->noisy && a->timestep && a->flow_out && a->x0_out, "sf_dit_forward: null tensor");
+  SF_CHECK(a->noisy && a->timestep, "sf_dit_forward: null tensor");
+  SF_CHECK(a->cache_only || (a->flow_out && a->x0_out), "sf_dit_forward: null output tensor");
   SF_CHECK(a->k_cache_host && a->v_cache_host && a->ck_cache_host && a->cv_cache_host, "sf_dit_forward: null cache table");
   SF_CHECK(a->attn_start >= 0 && a->attn_end > a->attn_start && a->attn_end <= a->cache_tokens, "sf_dit_forward: bad attention window [%d, %d) of %lld",
            a->attn_start, a->attn_end, (long long)a->cache_tokens);
@@ -142,6 +143,7 @@ extern "C" int sf_dit_forward(const sf_model* m, const sf_forward_args* a, void*
     }
     SF_TRY(sf_qkv_norm_rope_cache(ws.qkv, lw.norm_q_w, lw.norm_k_w, ws.q, a->k_cache_host[l], a->v_cache_host[l], m->rope_cos, m->rope_sin,
                                   B, F, h, w, C, m->num_heads, a->cache_tokens, a->write_start, a->start_frame, m->eps, stream));
+    if (a->cache_only && l == m->num_layers - 1) return 0;   // nothing downstream of this K/V write is read
     SF_TRY(sf_attention(ws.q, bptr(a->k_cache_host[l], (size_t)a->attn_start * C), bptr(a->v_cache_host[l], (size_t)a->attn_start * C), ws.att,
                         B, m->num_heads, L, a->attn_end - a->attn_start, C, (long)L * C, C, cache_b, C, (long)L * C, stream));
     SF_TRY(gemm(ws.att, C, lw.o_w, lw.o_b, ws.x, C, M, C, C, SF_EPI_BIAS_GATE_RESID, ws.x, C, bptr(mod, 2 * (size_t)C), bptr(ws.e0, 2 * (size_t)C),

@@ -118,7 +118,9 @@ class CausalWanModel:
 
     # ---------------------------------------------------------------------------------
     def workspace(self, B: int, F: int, H: int, W: int, G: int) -> Tensor:
-        key = (B, F, H, W, G)
+        # one workspace per shape AND stream: concurrent rollouts on different HIP streams share the
+        # weights but must not share activations
+        key = (B, F, H, W, G, torch.cuda.current_stream(self.device).cuda_stream)
         ws = self._workspaces.get(key)
         if ws is None:
             n = _lib.lib().sf_dit_workspace_bytes(C.byref(self.cmodel), B, F, H, W, G)
@@ -128,7 +130,7 @@ class CausalWanModel:
 
     def forward(self, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], init_cross: bool,
                 k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cache_tokens: int, plan: CachePlan, start_frame: int,
-                evict_scratch: Optional[Tensor] = None):
+                evict_scratch: Optional[Tensor] = None, cache_only: bool = False):
         """noisy [B,F,in_dim,H,W] bf16 (contiguous); timestep [B,G] float32|int64 on device;
         *_ptrs: ctypes arrays of per-layer cache pointers.  Returns (flow, x0) [B,F,out_dim,H,W]."""
         B, F, Cin, H, W = noisy.shape
@@ -148,9 +150,12 @@ class CausalWanModel:
         if evict_scratch is not None:
             a.evict_scratch = evict_scratch.data_ptr()
             a.evict_scratch_bytes = evict_scratch.numel() * evict_scratch.element_size()
-        flow = torch.empty(B, F, self.shape.out_dim, H, W, dtype=torch.bfloat16, device=self.device)
-        x0 = torch.empty_like(flow)
-        a.flow_out, a.x0_out = flow.data_ptr(), x0.data_ptr()
+        flow = x0 = None
+        a.cache_only = 1 if cache_only else 0
+        if not cache_only:
+            flow = torch.empty(B, F, self.shape.out_dim, H, W, dtype=torch.bfloat16, device=self.device)
+            x0 = torch.empty_like(flow)
+            a.flow_out, a.x0_out = flow.data_ptr(), x0.data_ptr()
         ws = self.workspace(B, F, H, W, G)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(_lib.lib().sf_dit_forward(C.byref(self.cmodel), C.byref(a), torch.cuda.current_stream().cuda_stream),

@@ -54,6 +54,13 @@ class CausalInferencePipeline(torch.nn.Module):
         # re-noise source; the reference calls torch.randn_like (causal_inference.py:208).  Tests and
         # the CPU-baseline comparison inject pre-drawn tensors here so both sides consume the same eps.
         self.noise_source: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+        # context / warm-up passes only update the KV cache; a generator that advertises `cache_only`
+        # (ours) may skip what nothing reads.  Foreign generators are called exactly as the reference does.
+        import inspect
+        try:
+            self._cache_only_kw = {"cache_only": True} if "cache_only" in inspect.signature(self.generator.forward).parameters else {}
+        except (TypeError, ValueError):
+            self._cache_only_kw = {}
         self.last_profile = None
         self._cache_key = None
 
@@ -108,7 +115,7 @@ class CausalInferencePipeline(torch.nn.Module):
                 output[:, :1] = initial_latent[:, :1]
                 gen(noisy_image_or_video=initial_latent[:, :1], conditional_dict=conditional_dict, timestep=timestep,
                     kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
-                    current_start=current_start_frame * self.frame_seq_length)
+                    current_start=current_start_frame * self.frame_seq_length, **self._cache_only_kw)
                 current_start_frame += 1
             else:
                 assert num_input_frames % self.num_frame_per_block == 0
@@ -118,7 +125,7 @@ class CausalInferencePipeline(torch.nn.Module):
                 output[:, current_start_frame:current_start_frame + self.num_frame_per_block] = ref
                 gen(noisy_image_or_video=ref, conditional_dict=conditional_dict, timestep=timestep,
                     kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
-                    current_start=current_start_frame * self.frame_seq_length)
+                    current_start=current_start_frame * self.frame_seq_length, **self._cache_only_kw)
                 current_start_frame += self.num_frame_per_block
 
         if profile:
@@ -157,7 +164,8 @@ class CausalInferencePipeline(torch.nn.Module):
             # rerun at the context timestep so the cache holds clean K/V (causal_inference.py:226-235)
             context_timestep = torch.ones_like(timestep) * ctx_noise
             gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
-                kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok)
+                kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok,
+                **self._cache_only_kw)
             if profile:
                 be.record()
                 block_events.append((bs, be))

@@ -83,6 +83,19 @@ class WanDiffusionWrapper(torch.nn.Module):
         self._ptr_cache: Dict[int, tuple] = {}
         self._evict_scratch: Optional[Tensor] = None
 
+    def share(self) -> "WanDiffusionWrapper":
+        """A second wrapper over the SAME device weights (own pointer tables / scratch), for a second
+        rollout running concurrently on another HIP stream."""
+        other = WanDiffusionWrapper.__new__(WanDiffusionWrapper)
+        torch.nn.Module.__init__(other)
+        other.uniform_timestep = self.uniform_timestep
+        other.scheduler = self.scheduler
+        other.model = self.model
+        other.seq_len = self.seq_len
+        other._ptr_cache = {}
+        other._evict_scratch = None
+        return other
+
     # --- reference API ------------------------------------------------------------------------
     def get_scheduler(self):
         return self.scheduler
@@ -140,7 +153,10 @@ class WanDiffusionWrapper(torch.nn.Module):
                 current_start: Optional[int] = None, classify_mode: Optional[bool] = False,
                 concat_time_embeddings: Optional[bool] = False, clean_x: Optional[Tensor] = None,
                 aug_t: Optional[Tensor] = None, cache_start: Optional[int] = None,
-                add_condition: Optional[Tensor] = None, clip_feature: Optional[Tensor] = None, y: Optional[Tensor] = None):
+                add_condition: Optional[Tensor] = None, clip_feature: Optional[Tensor] = None, y: Optional[Tensor] = None,
+                cache_only: bool = False):
+        """`cache_only=True` (extension): the caller only wants the KV-cache update (context pass,
+        initial-latent warm-up) and gets (None, None) back; see sf_forward_args.cache_only."""
         if kv_cache is None or crossattn_cache is None:
             raise NotImplementedError("only the KV-cached inference branch is implemented (kv_cache / crossattn_cache required)")
         if classify_mode or clean_x is not None or aug_t is not None:
@@ -200,7 +216,7 @@ class WanDiffusionWrapper(torch.nn.Module):
 
         k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = self._pointer_tables(kv_cache, crossattn_cache)
         flow, x0 = mdl.forward(x, t, pe, init_cross, k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cap, plan,
-                               current_start // fs, scratch)
+                               current_start // fs, scratch, cache_only=cache_only)
         if init_cross:
             for c in crossattn_cache:
                 c["is_init"] = True

@@ -198,3 +198,52 @@ def test_full_1p3b_forward_vs_reference_golden():
     assert e_flow < TOL and e_x0 < TOL
     assert rel(pipe.kv_cache1[0]["k"][0, :, 0], T(Gd["k0_head0_f32"])) < TOL
     assert rel(pipe.kv_cache1[29]["k"][0, :, 5], T(Gd["k29_head5_f32"])) < TOL
+
+
+def test_cache_only_pass_leaves_identical_caches(sd_reduced):
+    """The context pass may skip what nothing reads (sf_forward_args.cache_only): the KV caches
+    after it must equal those of a full pass bit for bit."""
+    shape = sfa.WAN_REDUCED
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, shape.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    t = torch.zeros(1, 2, dtype=torch.int64, device=DEV)
+    caches = []
+    for cache_only in (False, True):
+        pipe = make_pipe(sd_reduced, 1, False, 5.0, pe=pe)
+        pipe.frame_seq_length = FS
+        pipe._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=2 * FS)
+        pipe._initialize_crossattn_cache(1, torch.bfloat16, DEV)
+        out = pipe.generator(x, {"prompt_embeds": pe}, t, pipe.kv_cache1, pipe.crossattn_cache, 0, cache_only=cache_only)
+        assert (out == (None, None)) == cache_only
+        caches.append(pipe.kv_cache1)
+    for a, b in zip(*caches):
+        assert torch.equal(a["k"], b["k"]) and torch.equal(a["v"], b["v"])
+        assert int(a["local_end_index"]) == int(b["local_end_index"]) == 2 * FS
+
+
+def test_two_concurrent_streams_match_sequential(sd_reduced):
+    """RolloutPool: two rollouts in flight on two HIP streams (shared weights, own caches and
+    workspaces) give the same latents as running them one after the other."""
+    shape = sfa.WAN_REDUCED
+    g = torch.Generator().manual_seed(13)
+    jobs = []
+    for j in range(4):
+        noise = torch.randn(1, 3, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16)
+        eps = [torch.randn(1, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(9)]
+        jobs.append((f"prompt {j}", noise, eps))
+    args = SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                           independent_first_frame=False, num_frame_per_block=1, context_noise=0)
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd_reduced, timestep_shift=5.0, is_causal=True, device=DEV)
+    enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=DEV)
+
+    def roll(pipe, job):
+        prompt, noise, eps = job
+        q = list(eps)
+        pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+        return pipe.inference(noise.to(DEV), [prompt], return_latents=True)[1].clone()
+
+    seq = sfa.RolloutPool(args, DEV, gen, lambda: enc, sfa.IdentityVAE, streams=1).run(jobs, roll)
+    par = sfa.RolloutPool(args, DEV, gen, lambda: enc, sfa.IdentityVAE, streams=2).run(jobs, roll)
+    for a, b in zip(seq, par):
+        assert torch.equal(a, b)
