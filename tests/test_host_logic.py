@@ -224,3 +224,104 @@ def test_two_rank_gloo_protocol(tmp_path):
     assert out["idx"] == [[0, 2, 4], [1, 3, 5]]
     assert out["elapsed"] >= 0.1 - 1e-3          # max over ranks: rank 1 slept 0.1 s
     assert out["frames"] == 2 * 3 * 81
+
+
+# ----------------------------------------------------------------------------------- config
+def test_config_merge_and_pipeline_selection(tmp_path):
+    from self_forcing_amd.config import load_config, is_few_step
+    d = tmp_path / "default.yaml"
+    d.write_text("independent_first_frame: false\nwarp_denoising_step: false\ncontext_noise: 0\nmodel_kwargs:\n  timestep_shift: 8.0\n  sink_size: 0\n")
+    r = tmp_path / "run.yaml"
+    r.write_text("denoising_step_list: [1000, 750, 500, 250]\nwarp_denoising_step: true\nnum_frame_per_block: 3\nmodel_kwargs:\n  timestep_shift: 5.0\n")
+    cfg = load_config(str(r), str(d))
+    assert cfg.warp_denoising_step is True and cfg.independent_first_frame is False and cfg.num_frame_per_block == 3
+    assert cfg.model_kwargs == {"timestep_shift": 5.0, "sink_size": 0}          # nested merge, run config wins
+    assert is_few_step(cfg) and hasattr(cfg, "denoising_step_list") and getattr(cfg, "nope", 7) == 7
+    assert not is_few_step(load_config(str(d)))
+    hot = load_config(os.path.join(ROOT, "configs", "self_forcing_dmd_hotpath.yaml"))
+    assert hot.denoising_step_list == [1000, 750, 500, 250] and hot.model_kwargs["timestep_shift"] == 5.0
+
+
+class _StubModel:
+    num_layers, local_attn_size, sink_size, num_frame_per_block = 2, -1, 0, 1
+    shape = sfa.WAN_REDUCED
+
+
+class _StubGenerator:
+    """Records the calls the pipeline makes (the reference's own test style: injected stand-ins,
+    test_lazy_load.py:84-92)."""
+
+    def __init__(self):
+        self.model = _StubModel()
+        self.scheduler = sfa.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+        self.scheduler.set_timesteps(1000, training=True)
+        self.scheduler.add_noise = lambda x0, eps, t: x0 + 0 * eps          # keep it on the CPU
+        self.calls = []
+
+    def get_scheduler(self):
+        return self.scheduler
+
+    def forward(self, noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache, current_start, cache_only=False):
+        self.calls.append((tuple(noisy_image_or_video.shape), timestep.flatten().tolist(), current_start, bool(cache_only)))
+        return noisy_image_or_video, noisy_image_or_video * 0.5
+
+    __call__ = forward
+
+
+@pytest.mark.parametrize("iff,nfpb,frames,initial", [(False, 3, 6, 0), (True, 3, 4, 0), (False, 1, 2, 0), (True, 3, 3, 1), (False, 3, 3, 3)])
+def test_pipeline_call_sequence_on_cpu(iff, nfpb, frames, initial):
+    """The rollout loop's bookkeeping (chunking, warped timesteps, current_start, context pass,
+    warm-up passes) without a GPU: causal_inference.py:72-244."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, independent_first_frame=iff,
+                           num_frame_per_block=nfpb, context_noise=0)
+    gen = _StubGenerator()
+    pipe = sfa.CausalInferencePipeline(args, "cpu", generator=gen, text_encoder=lambda text_prompts: {"prompt_embeds": None},
+                                       vae=sfa.IdentityVAE())
+    assert [round(float(v), 2) for v in pipe.denoising_step_list] == [1000.0, 937.5, 833.33, 625.0]
+    noise = torch.randn(1, frames, 16, 8, 12)
+    init = torch.randn(1, initial, 16, 8, 12) if initial else None
+    video, lat = pipe.inference(noise, ["p"], initial_latent=init, return_latents=True)
+    fs = 24
+    assert pipe.frame_seq_length == fs and lat.shape[1] == frames + initial
+    chunks = ([1] if (iff and not initial) else []) + [nfpb] * ((frames - (1 if iff and not initial else 0)) // nfpb)
+    warm = []
+    if initial:
+        if iff:
+            warm.append(1)
+        warm += [nfpb] * ((initial - (1 if iff else 0)) // nfpb)
+    assert len(gen.calls) == len(warm) + 5 * len(chunks)
+    start, k = 0, 0
+    for f in warm:                                  # warm-up: t = 0, ONE timestep group, cache only
+        shp, ts, cs, co = gen.calls[k]
+        assert shp[1] == f and ts == [0] and cs == start * fs and co
+        start += f
+        k += 1
+    for f in chunks:
+        for i, want in enumerate([1000.0, 937.5, 833.3333129882812, 625.0, 0.0]):
+            shp, ts, cs, co = gen.calls[k]
+            assert shp[1] == f and cs == start * fs and len(ts) == f and all(abs(t - want) < 1e-3 for t in ts)
+            assert co == (i == 4)                   # only the context pass may skip its outputs
+            k += 1
+        start += f
+    if initial:
+        assert torch.equal(lat[:, :initial], init)
+
+
+def test_pipeline_calls_foreign_generator_like_the_reference():
+    """A generator without the `cache_only` extension is called with the reference's keywords only."""
+    from types import SimpleNamespace
+
+    class Plain(_StubGenerator):
+        def forward(self, noisy_image_or_video, conditional_dict, timestep, kv_cache, crossattn_cache, current_start):
+            self.calls.append(current_start)
+            return noisy_image_or_video, noisy_image_or_video
+        __call__ = forward
+
+    args = SimpleNamespace(denoising_step_list=[1000, 500], warp_denoising_step=False, independent_first_frame=False,
+                           num_frame_per_block=1, context_noise=0)
+    gen = Plain()
+    pipe = sfa.CausalInferencePipeline(args, "cpu", generator=gen, text_encoder=lambda text_prompts: {}, vae=sfa.IdentityVAE())
+    assert pipe.denoising_step_list.dtype == torch.long          # un-warped list stays integer (SURVEY A.6)
+    pipe.inference(torch.randn(1, 2, 16, 8, 12), ["p"])
+    assert gen.calls == [0, 0, 0, 24, 24, 24]
