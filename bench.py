@@ -104,9 +104,16 @@ def roofline_leg(shape, dev, frames, nfpb, fs):
         flops.append(4.0 * shape.dim * n * lk)
     avg_ms = sum(durs) / len(durs)
     avg_flops = sum(flops) / len(flops)
-    att = {"bound": "mfma", "kernel": "attention_kernel<0> (self-attention over the KV cache)",
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same shapes
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)["attention_w8_kernel<0>"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    att = {"bound": "mfma", "kernel": "attention_w8_kernel<0> (self-attention over the KV cache)",
            "achieved": avg_flops / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+           "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
+           "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the same 7 cache lengths)",
            "avg_launch_ms": avg_ms, "flops_per_launch": avg_flops,
            "per_lk_tflops": {str((i + 1) * n): flops[i] / (durs[i] * 1e-3) / 1e12 for i in range(len(durs))}}
     # GEMMs: ffn.0 (N = ffn_dim) and ffn.2 (K = ffn_dim) at M = n
