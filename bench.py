@@ -267,6 +267,23 @@ def main():
         att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs)
         out["roofline"] = att
         out["gemm"] = gemm
+    if rank == 0 and not a.no_roofline:
+        # streaming boundary: chunk-at-a-time generation on one stream, wall time per chunk
+        log("streaming leg")
+        pipe0 = pool.pipes[0]
+        noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        ts, t_prev = [], time.perf_counter()
+        for _idx, lat_chunk, _pix in pipe0.stream(noise, [prompts[0]]):
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            ts.append(now - t_prev)
+            t_prev = now
+        steady = ts[1:] if len(ts) > 1 else ts
+        out["streaming"] = {"first_chunk_ms": 1e3 * ts[0], "chunk_ms": [round(1e3 * t, 1) for t in ts],
+                            "decoded_frames_per_chunk": 4 * nfpb, "steady_fps": 4 * nfpb * len(steady) / sum(steady),
+                            "worst_chunk_fps": 4 * nfpb / max(steady), "realtime_playback_fps": 16,
+                            "note": "one rollout alone on the GPU; chunk k can be decoded/sent while k+1 is generated"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(shape, sd, 1, nfpb, len(step_list), a.frames)
     if dist is not None:

@@ -162,6 +162,8 @@ typedef struct sf_model {
   const void *tproj_w, *tproj_b;          /* [6C, C] */
   const void *head_w, *head_b;            /* [4*out_dim, C] */
   const void* head_mod;                   /* [2, C] */
+  const void *pose_w, *pose_b;            /* optional pose_proj Linear(pose_dim, C) (causal_model.py:493-503); NULL if absent */
+  int32_t pose_dim;
   const sf_layer_weights* layers_host;    /* HOST array [num_layers] */
   const float *rope_cos, *rope_sin;       /* float32 [1024, 64] */
   const float *sched_sigmas, *sched_timesteps; /* float32 [n_table] */
@@ -176,6 +178,8 @@ typedef struct sf_forward_args {
   int32_t t_is_int64;
   const void* prompt_embeds;              /* [B, text_len, text_dim], zero padded; read only if init_cross */
   int32_t init_cross;                     /* 1: (re)compute text embedding + cross-attn K/V caches */
+  const void* add_condition;              /* optional pose tokens [B, F*h*w, pose_dim]: x += pose_proj(add_condition)
+                                             after the patch embedding (causal_model.py:786-819); NULL if none */
   void* const* k_cache_host;              /* HOST arrays [num_layers] of device pointers */
   void* const* v_cache_host;              /*   each [B, cache_tokens, H, D]              */
   void* const* ck_cache_host;             /*   each [B, text_len, H, D]                  */

@@ -346,7 +346,7 @@ def text_embedding(W: Dict[str, Tensor], cfg: OracleConfig, context: Tensor) -> 
 
 def forward_inference(W: Dict[str, Tensor], cfg: OracleConfig, x: Tensor, t: Tensor,
                       context: Tensor, kv_cache: List[dict], crossattn_cache: List[dict],
-                      current_start: int, rope=None) -> Tensor:
+                      current_start: int, rope=None, add_condition: Optional[Tensor] = None) -> Tensor:
     """CausalWanModel._forward_inference, wan/modules/causal_model.py:725-893.
     x: [B, C_in, F, H, W]; t: [B, G]; context: [B, <=text_len, text_dim]
     -> flow [B, C_out, F, H, W]."""
@@ -354,6 +354,15 @@ def forward_inference(W: Dict[str, Tensor], cfg: OracleConfig, x: Tensor, t: Ten
     if rope is None:
         rope = rope_tables(cfg.head_dim)
     tok, grid = patch_embed(W, cfg, x.to(dtype))
+    if add_condition is not None:
+        # Pose tokens of the fork, causal_model.py:786-819: x += pose_proj(add_condition), lengths must match.
+        # PARITY UNPINNED for this branch: in the reference snapshot the inference path itself raises at
+        # causal_model.py:794 (`x.view(B, L, C)` with L computed from an already-batched [B, L, C] tensor), so
+        # no reference output exists; this restates the evident intent, identical to the arithmetic of the
+        # training branch (causal_model.py:980-994).
+        if add_condition.shape[1] != tok.shape[1]:
+            raise ValueError(f"add_condition spatial dim {add_condition.shape[1]} doesn't match x spatial dim {tok.shape[1]}")
+        tok = tok + F.linear(add_condition.to(dtype), W["pose_proj.weight"], W["pose_proj.bias"])
     e, e0 = time_embeddings(W, cfg, t, dtype)
     ctx = text_embedding(W, cfg, context.to(dtype))
     h = tok
@@ -401,11 +410,11 @@ def flow_to_x0(sched: FlowMatchTables, flow: Tensor, xt: Tensor, timestep: Tenso
 
 
 def wrapper_forward(W, cfg: OracleConfig, sched: FlowMatchTables, noisy: Tensor, prompt_embeds: Tensor,
-                    timestep: Tensor, kv_cache, crossattn_cache, current_start: int, rope=None):
+                    timestep: Tensor, kv_cache, crossattn_cache, current_start: int, rope=None, add_condition=None):
     """WanDiffusionWrapper.forward, kv branch -- utils/wan_wrapper.py:253-300, 340-349.
     noisy [B, F, C, H, W]; timestep [B, G] -> (flow_pred, pred_x0), both [B, F, C, H, W]."""
     flow = forward_inference(W, cfg, noisy.permute(0, 2, 1, 3, 4), timestep, prompt_embeds,
-                             kv_cache, crossattn_cache, current_start, rope).permute(0, 2, 1, 3, 4)
+                             kv_cache, crossattn_cache, current_start, rope, add_condition).permute(0, 2, 1, 3, 4)
     # timestep.flatten(0,1) has B*G entries; with G == F this is one sigma per frame.
     x0 = flow_to_x0(sched, flow.flatten(0, 1), noisy.flatten(0, 1).to(flow.dtype),
                     timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])

@@ -45,7 +45,8 @@ class Model(C.Structure):
         + [("eps", C.c_float)]
         + [(n, C.c_void_p) for n in ("patch_w", "patch_b", "text0_w", "text0_b", "text2_w", "text2_b",
                                      "time0_w", "time0_b", "time2_w", "time2_b", "tproj_w", "tproj_b",
-                                     "head_w", "head_b", "head_mod")]
+                                     "head_w", "head_b", "head_mod", "pose_w", "pose_b")]
+        + [("pose_dim", C.c_int32)]
         + [("layers_host", C.POINTER(LayerWeights)),
            ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
            ("sched_sigmas", C.c_void_p), ("sched_timesteps", C.c_void_p),
@@ -58,7 +59,7 @@ class ForwardArgs(C.Structure):
         ("batch", C.c_int32), ("frames", C.c_int32), ("lat_h", C.c_int32), ("lat_w", C.c_int32),
         ("groups", C.c_int32),
         ("noisy", C.c_void_p), ("timestep", C.c_void_p), ("t_is_int64", C.c_int32),
-        ("prompt_embeds", C.c_void_p), ("init_cross", C.c_int32),
+        ("prompt_embeds", C.c_void_p), ("init_cross", C.c_int32), ("add_condition", C.c_void_p),
         ("k_cache_host", C.POINTER(C.c_void_p)), ("v_cache_host", C.POINTER(C.c_void_p)),
         ("ck_cache_host", C.POINTER(C.c_void_p)), ("cv_cache_host", C.POINTER(C.c_void_p)),
         ("cache_tokens", C.c_int64),

@@ -108,6 +108,12 @@ extern "C" int sf_dit_forward(const sf_model* m, const sf_forward_args* a, void*
   SF_TRY(sf_patchify(a->noisy, ws.cols, B, F, m->in_dim, a->lat_h, a->lat_w, stream));
   SF_TRY(gemm(ws.cols, Kp, m->patch_w, m->patch_b, ws.x, C, M, C, Kp, SF_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 1, stream));
 
+  // ---- pose conditioning of the fork: x += pose_proj(add_condition)  (causal_model.py:786-819)
+  if (a->add_condition) {
+    SF_CHECK(m->pose_w && m->pose_dim > 0, "sf_dit_forward: add_condition given but the model has no pose_proj weights");
+    SF_TRY(gemm(a->add_condition, m->pose_dim, m->pose_w, m->pose_b, ws.x, C, M, C, m->pose_dim, SF_EPI_BIAS_RESID, ws.x, C, nullptr, nullptr, 0, 1, stream));
+  }
+
   // ---- time embeddings: e [BG, C], e0 [BG, 6C]
   SF_TRY(sf_sinusoid_embedding(a->timestep, a->t_is_int64, ws.sin, BG, m->freq_dim, stream));
   SF_TRY(sf_small_linear(ws.sin, m->time0_w, m->time0_b, ws.etmp, BG, C, m->freq_dim, 0, 1, stream));

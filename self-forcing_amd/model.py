@@ -83,6 +83,10 @@ class CausalWanModel:
             setattr(m, dst + "_w", P(self._dev(sd[src + ".weight"])))
             setattr(m, dst + "_b", P(self._dev(sd[src + ".bias"])))
         m.head_mod = P(self._dev(sd["head.modulation"].reshape(2, s.dim)))
+        self.has_pose_proj = "pose_proj.weight" in sd
+        if self.has_pose_proj:   # optional: the fork's pose conditioning (Linear(5120, dim), causal_model.py:493-503)
+            m.pose_w, m.pose_b = P(self._dev(sd["pose_proj.weight"])), P(self._dev(sd["pose_proj.bias"]))
+            m.pose_dim = sd["pose_proj.weight"].shape[1]
         layers = (_lib.LayerWeights * s.num_layers)()
         for i in range(s.num_layers):
             p = f"blocks.{i}."
@@ -130,7 +134,7 @@ class CausalWanModel:
 
     def forward(self, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], init_cross: bool,
                 k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cache_tokens: int, plan: CachePlan, start_frame: int,
-                evict_scratch: Optional[Tensor] = None, cache_only: bool = False):
+                evict_scratch: Optional[Tensor] = None, cache_only: bool = False, add_condition: Optional[Tensor] = None):
         """noisy [B,F,in_dim,H,W] bf16 (contiguous); timestep [B,G] float32|int64 on device;
         *_ptrs: ctypes arrays of per-layer cache pointers.  Returns (flow, x0) [B,F,out_dim,H,W]."""
         B, F, Cin, H, W = noisy.shape
@@ -142,6 +146,7 @@ class CausalWanModel:
         a.t_is_int64 = 1 if timestep.dtype == torch.int64 else 0
         a.prompt_embeds = prompt_embeds.data_ptr() if prompt_embeds is not None else None
         a.init_cross = 1 if init_cross else 0
+        a.add_condition = add_condition.data_ptr() if add_condition is not None else None
         a.k_cache_host, a.v_cache_host, a.ck_cache_host, a.cv_cache_host = k_ptrs, v_ptrs, ck_ptrs, cv_ptrs
         a.cache_tokens = cache_tokens
         a.sink_tokens, a.evict, a.keep = plan.sink, plan.evict, plan.keep

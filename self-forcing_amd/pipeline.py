@@ -136,40 +136,11 @@ class CausalInferencePipeline(torch.nn.Module):
         all_num_frames = [self.num_frame_per_block] * num_blocks
         if self.independent_first_frame and initial_latent is None:
             all_num_frames = [1] + all_num_frames
-        steps = self.denoising_step_list
-        ctx_noise = getattr(self.args, "context_noise", 0)
-        for current_num_frames in all_num_frames:
-            if profile:
-                bs, be = ev(), ev()
-                bs.record()
-            noisy_input = noise[:, current_start_frame - num_input_frames:
-                                current_start_frame + current_num_frames - num_input_frames]
-            start_tok = current_start_frame * self.frame_seq_length
-            for index, current_timestep in enumerate(steps):
-                timestep = torch.ones([batch_size, current_num_frames], device=noise.device, dtype=torch.int64) \
-                    * current_timestep.to(noise.device)
-                _, denoised_pred = gen(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
-                                       timestep=timestep, kv_cache=self.kv_cache1,
-                                       crossattn_cache=self.crossattn_cache, current_start=start_tok)
-                if index < len(steps) - 1:
-                    next_timestep = steps[index + 1].to(noise.device)
-                    flat = denoised_pred.flatten(0, 1)
-                    noisy_input = self.scheduler.add_noise(
-                        flat, self._randn_like(flat),
-                        next_timestep * torch.ones([batch_size * current_num_frames], device=noise.device, dtype=torch.long)
-                    ).unflatten(0, denoised_pred.shape[:2])
-
-            output[:, current_start_frame:current_start_frame + current_num_frames] = denoised_pred
-
-            # rerun at the context timestep so the cache holds clean K/V (causal_inference.py:226-235)
-            context_timestep = torch.ones_like(timestep) * ctx_noise
-            gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
-                kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok,
-                **self._cache_only_kw)
-            if profile:
-                be.record()
-                block_events.append((bs, be))
-            current_start_frame += current_num_frames
+        for chunk_idx, start_frame, denoised_pred in self._denoise_chunks(
+                noise, conditional_dict, all_num_frames, current_start_frame, num_input_frames, skip_last_context=False,
+                on_chunk_start=(lambda: block_events.append([ev(), ev()]) or block_events[-1][0].record()) if profile else None,
+                on_chunk_end=(lambda: block_events[-1][1].record()) if profile else None):
+            output[:, start_frame:start_frame + denoised_pred.shape[1]] = denoised_pred
 
         if profile:
             diffusion_end.record()
@@ -200,6 +171,76 @@ class CausalInferencePipeline(torch.nn.Module):
         if return_latents:
             return video, output
         return video
+
+    # ------------------------------------------------------------------------------------------
+    def _denoise_chunks(self, noise, conditional_dict, all_num_frames, current_start_frame, num_input_frames,
+                        skip_last_context, on_chunk_start=None, on_chunk_end=None):
+        """The chunk loop of causal_inference.py:176-244 as a generator: yields
+        (chunk_index, start_frame, x0 [B, f, C, H, W]) as soon as a chunk's last denoising step is
+        enqueued; the context pass that rewrites the chunk's K/V "clean" follows (and is skipped for
+        the final chunk when `skip_last_context`, as demo.py:396 does: nothing reads that update)."""
+        gen = self.generator
+        batch_size = noise.shape[0]
+        steps = self.denoising_step_list
+        ctx_noise = getattr(self.args, "context_noise", 0)
+        for chunk_idx, current_num_frames in enumerate(all_num_frames):
+            if on_chunk_start is not None:
+                on_chunk_start()
+            noisy_input = noise[:, current_start_frame - num_input_frames:
+                                current_start_frame + current_num_frames - num_input_frames]
+            start_tok = current_start_frame * self.frame_seq_length
+            for index, current_timestep in enumerate(steps):
+                timestep = torch.ones([batch_size, current_num_frames], device=noise.device, dtype=torch.int64) \
+                    * current_timestep.to(noise.device)
+                _, denoised_pred = gen(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
+                                       timestep=timestep, kv_cache=self.kv_cache1,
+                                       crossattn_cache=self.crossattn_cache, current_start=start_tok)
+                if index < len(steps) - 1:
+                    next_timestep = steps[index + 1].to(noise.device)
+                    flat = denoised_pred.flatten(0, 1)
+                    noisy_input = self.scheduler.add_noise(
+                        flat, self._randn_like(flat),
+                        next_timestep * torch.ones([batch_size * current_num_frames], device=noise.device, dtype=torch.long)
+                    ).unflatten(0, denoised_pred.shape[:2])
+            yield chunk_idx, current_start_frame, denoised_pred
+            # rerun at the context timestep so the cache holds clean K/V (causal_inference.py:226-235)
+            if not (skip_last_context and chunk_idx == len(all_num_frames) - 1):
+                context_timestep = torch.ones_like(timestep) * ctx_noise
+                gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
+                    kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok,
+                    **self._cache_only_kw)
+            if on_chunk_end is not None:
+                on_chunk_end()
+            current_start_frame += current_num_frames
+
+    def stream(self, noise: torch.Tensor, text_prompts: List[str], skip_last_context: bool = True):
+        """Chunk-at-a-time generation (the streaming boundary; mirrors the inline loop of the
+        reference's demo.py:303-468): yields `(chunk_index, latents [B, f, C, H, W], pixels)` per chunk
+        as soon as it is denoised, so a consumer can decode / send chunk k while chunk k+1 is being
+        generated.  `pixels` comes from `vae.decode_chunk(latents, chunk_index)` when the injected VAE
+        has a streaming decoder, else from `decode_to_pixel` on the chunk alone."""
+        batch_size, num_frames, num_channels, height, width = noise.shape
+        if self.independent_first_frame:
+            assert (num_frames - 1) % self.num_frame_per_block == 0
+            all_num_frames = [1] + [self.num_frame_per_block] * ((num_frames - 1) // self.num_frame_per_block)
+        else:
+            assert num_frames % self.num_frame_per_block == 0
+            all_num_frames = [self.num_frame_per_block] * (num_frames // self.num_frame_per_block)
+        self.frame_seq_length = (height // 2) * (width // 2)
+        conditional_dict = self.text_encoder(text_prompts=text_prompts)
+        key = (batch_size, self._cache_tokens(num_frames), noise.device)
+        if self.kv_cache1 is None or self._cache_key != key:
+            self._initialize_kv_cache(batch_size, noise.dtype, noise.device, cache_tokens=key[1])
+            self._initialize_crossattn_cache(batch_size, noise.dtype, noise.device)
+            self._cache_key = key
+        else:
+            for block_index in range(self.num_transformer_blocks):
+                self.crossattn_cache[block_index]["is_init"] = False
+            self._reset_kv_indices()
+        decode_chunk = getattr(self.vae, "decode_chunk", None)
+        for chunk_idx, start_frame, x0 in self._denoise_chunks(noise, conditional_dict, all_num_frames, 0, 0, skip_last_context):
+            pixels = decode_chunk(x0, chunk_idx) if decode_chunk is not None else self.vae.decode_to_pixel(x0, use_cache=False)
+            yield chunk_idx, x0, (pixels * 0.5 + 0.5).clamp(0, 1)
 
     # ------------------------------------------------------------------------------------------
     def _cache_tokens(self, total_frames: Optional[int] = None) -> int:

@@ -13,8 +13,8 @@ Differences from the reference, all deliberate:
   * the attention window for `local_attn_size == -1` is the cache capacity and for rolling mode
     `local_attn_size * frame_seqlen` of the CURRENT latent size (the reference hard-codes
     32760 / `local_attn_size * 1560`, causal_model.py:77, which is only right for 60x104 latents);
-  * the non-cached branches (`kv_cache is None`, classify_mode, clean_x teacher forcing) and
-    `add_condition` belong to training / the pose fork and raise NotImplementedError.
+  * the non-cached branches (`kv_cache is None`, classify_mode, clean_x teacher forcing) and the i2v inputs
+    (`clip_feature`, `y`) raise NotImplementedError; the fork's pose tokens (`add_condition`) are supported.
 """
 from __future__ import annotations
 
@@ -163,9 +163,9 @@ class WanDiffusionWrapper(torch.nn.Module):
             raise NotImplementedError("training-only branches (classify_mode / teacher forcing) are out of scope")
         if add_condition is None:
             add_condition = conditional_dict.get("add_condition")
-        if add_condition is not None or clip_feature is not None or y is not None \
+        if clip_feature is not None or y is not None \
                 or conditional_dict.get("clip_feature") is not None or conditional_dict.get("y") is not None:
-            raise NotImplementedError("pose / image conditioning (add_condition, clip_feature, y) is not implemented yet")
+            raise NotImplementedError("image conditioning (clip_feature, y: the i2v model type) is not implemented")
         mdl = self.model
         shape = mdl.shape
         x = noisy_image_or_video
@@ -214,9 +214,19 @@ class WanDiffusionWrapper(torch.nn.Module):
                 pe = torch.cat([pe, pe.new_zeros(B, shape.text_len - pe.shape[1], shape.text_dim)], dim=1)
             pe = pe.contiguous()
 
+        if add_condition is not None:   # pose tokens [B, L_pose, 5120]: x += pose_proj(add_condition), the intent of
+            # causal_model.py:786-819 (that branch raises in the reference snapshot: parity pinned by the oracle only)
+            if not mdl.has_pose_proj:
+                raise NotImplementedError("add_condition needs pose_proj weights in the state dict "
+                                          "(dim == 5120 models use an identity projection, which is not implemented)")
+            add_condition = add_condition.to(device=mdl.device, dtype=torch.bfloat16).contiguous()
+            if add_condition.dim() != 3 or add_condition.shape[0] != B or add_condition.shape[1] != n_new:
+                raise ValueError(f"add_condition spatial dim {add_condition.shape[1]} doesn't match "
+                                 f"x spatial dim {n_new}. Check pose data processing.")
+            assert add_condition.shape[2] == mdl.cmodel.pose_dim, "add_condition channel width must match pose_proj"
         k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = self._pointer_tables(kv_cache, crossattn_cache)
         flow, x0 = mdl.forward(x, t, pe, init_cross, k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cap, plan,
-                               current_start // fs, scratch, cache_only=cache_only)
+                               current_start // fs, scratch, cache_only=cache_only, add_condition=add_condition)
         if init_cross:
             for c in crossattn_cache:
                 c["is_init"] = True

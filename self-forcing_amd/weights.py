@@ -55,8 +55,12 @@ WAN_REDUCED = WanShape(dim=512, ffn_dim=1024, num_heads=4, num_layers=2, text_di
 NAMED_SHAPES = {"Wan2.1-T2V-1.3B": WAN_1_3B, "Wan2.1-T2V-14B": WAN_14B, "reduced": WAN_REDUCED}
 
 
-def param_shapes(s: WanShape) -> Dict[str, Tuple[int, ...]]:
-    """Every tensor the hot path reads, with its shape."""
+POSE_DIM = 5120  # UniAnimate pose-embedding width (causal_model.py:493-503)
+
+
+def param_shapes(s: WanShape, pose: bool = False) -> Dict[str, Tuple[int, ...]]:
+    """Every tensor the hot path reads, with its shape.  `pose=True` appends the optional
+    `pose_proj` Linear(5120, dim) of the fork's pose conditioning (Identity when dim == 5120)."""
     C, Fd = s.dim, s.ffn_dim
     P = s.patch_size[0] * s.patch_size[1] * s.patch_size[2]
     out: Dict[str, Tuple[int, ...]] = {
@@ -85,11 +89,14 @@ def param_shapes(s: WanShape) -> Dict[str, Tuple[int, ...]]:
         out[p + "ffn.0.bias"] = (Fd,)
         out[p + "ffn.2.weight"] = (C, Fd)
         out[p + "ffn.2.bias"] = (C,)
+    if pose and C != POSE_DIM:   # appended LAST: the seeded draws of all other tensors do not move
+        out["pose_proj.weight"] = (C, POSE_DIM)
+        out["pose_proj.bias"] = (C,)
     return out
 
 
 def synth_state_dict(s: WanShape, seed: int = 0, dtype=torch.bfloat16,
-                     modulation_gain: float = 1.0) -> Dict[str, Tensor]:
+                     modulation_gain: float = 1.0, pose: bool = False) -> Dict[str, Tensor]:
     """Seeded random-init weights on the CPU (SURVEY.md section 8d recipe).
 
     Follows the distributions of `CausalWanModel.init_weights`
@@ -102,7 +109,7 @@ def synth_state_dict(s: WanShape, seed: int = 0, dtype=torch.bfloat16,
     """
     g = torch.Generator(device="cpu").manual_seed(seed)
     sd: Dict[str, Tensor] = {}
-    for name, shape in param_shapes(s).items():
+    for name, shape in param_shapes(s, pose).items():
         if name.endswith("modulation"):
             t = torch.randn(shape, generator=g) * (modulation_gain / math.sqrt(s.dim))
         elif name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm3.weight"):

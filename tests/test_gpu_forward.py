@@ -247,3 +247,62 @@ def test_two_concurrent_streams_match_sequential(sd_reduced):
     par = sfa.RolloutPool(args, DEV, gen, lambda: enc, sfa.IdentityVAE, streams=2).run(jobs, roll)
     for a, b in zip(seq, par):
         assert torch.equal(a, b)
+
+
+def test_streaming_matches_batch_inference(sd_reduced):
+    """`stream()` (chunk-at-a-time, last context pass skipped as demo.py:396 does) yields exactly the
+    latents `inference()` returns."""
+    g = torch.Generator().manual_seed(31)
+    noise = torch.randn(1, 6, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    eps = [torch.randn(3, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(6)]
+    pipe = make_pipe(sd_reduced, 3, False, 5.0, pe=pe)
+    q = list(eps)
+    pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+    _, lat = pipe.inference(noise, ["p"], return_latents=True)
+    q.extend(eps)
+    chunks = list(pipe.stream(noise, ["p"]))
+    assert [c[0] for c in chunks] == [0, 1] and all(c[1].shape[1] == 3 for c in chunks)
+    assert torch.equal(torch.cat([c[1] for c in chunks], dim=1), lat)
+    assert torch.equal(chunks[1][2], (chunks[1][1] * 0.5 + 0.5).clamp(0, 1))
+    # the skipped pass would only have rewritten the last chunk's K/V: indices still cover all tokens
+    assert int(pipe.kv_cache1[0]["global_end_index"]) == 6 * FS
+
+
+def test_add_condition_pose_tokens_vs_oracle():
+    """x += pose_proj(add_condition) after the patch embedding (the intent of causal_model.py:786-819).
+    Parity for this branch is pinned by the oracle restatement only: the reference's own inference
+    branch raises on it (see oracle/wan_oracle.py)."""
+    shape = sfa.WAN_REDUCED
+    sd = sfa.synth_state_dict(shape, seed=0, pose=True)
+    assert torch.equal(sd["head.head.weight"], sfa.synth_state_dict(shape, seed=0)["head.head.weight"])
+    g = torch.Generator().manual_seed(55)
+    pe = torch.randn(1, 512, shape.text_dim, generator=g).to(torch.bfloat16)
+    x = torch.randn(1, 2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16)
+    cond = (0.5 * torch.randn(1, 2 * FS, 5120, generator=g)).to(torch.bfloat16)
+    t = torch.tensor([[833.3333129882812, 625.0]])
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=5.0, is_causal=True, device=DEV)
+    args = SimpleNamespace(denoising_step_list=[1000], warp_denoising_step=False, independent_first_frame=False,
+                           num_frame_per_block=1, context_noise=0)
+    pipe = sfa.CausalInferencePipeline(args, DEV, generator=gen, text_encoder=sfa.FixedTextEncoder(pe.to(DEV)), vae=sfa.IdentityVAE())
+    pipe.frame_seq_length = FS
+    outs = []
+    for c in (cond, None):
+        pipe._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=2 * FS)
+        pipe._initialize_crossattn_cache(1, torch.bfloat16, DEV)
+        cd = {"prompt_embeds": pe.to(DEV)}
+        if c is not None:
+            cd["add_condition"] = c.to(DEV)          # the reference passes it through the conditional dict
+        outs.append(gen(x.to(DEV), cd, t.to(DEV), pipe.kv_cache1, pipe.crossattn_cache, 0)[0])
+    Wf = wo.prepare_weights(sd, torch.float32)
+    cfg = wo.OracleConfig(dim=shape.dim, ffn_dim=shape.ffn_dim, num_heads=shape.num_heads, num_layers=shape.num_layers,
+                          text_dim=shape.text_dim)
+    for out, c in zip(outs, (cond, None)):
+        kv, ca = wo.init_kv_cache(cfg, 1, 2 * FS, torch.float32), wo.init_crossattn_cache(cfg, 1, torch.float32)
+        ref = wo.wrapper_forward(Wf, cfg, wo.FlowMatchTables(5.0), x.float(), pe.float(), t, kv, ca, 0,
+                                 add_condition=None if c is None else c.float())[0]
+        assert rel(out, ref) < TOL
+    assert rel(outs[0], outs[1]) > 0.05              # the condition really changes the result
+    with pytest.raises(ValueError, match="spatial dim"):
+        gen(x.to(DEV), {"prompt_embeds": pe.to(DEV), "add_condition": cond[:, :-1].to(DEV)}, t.to(DEV), pipe.kv_cache1,
+            pipe.crossattn_cache, 0)
