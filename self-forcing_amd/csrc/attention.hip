@@ -311,9 +311,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
 // pairing "QK^T + softmax" with "PV" does not help either: the two MFMA streams share the pipe,
 // finish together and leave the softmax alone.
 // (A 64-rows-per-wave variant -- every K/V fragment feeding two MFMAs, 19 instead of 34 LDS bytes
-// per kflop -- was built and measured at 557 TFLOP/s: with 512 registers per wave hipcc parks
-// accumulators in AGPRs and pays hundreds of v_accvgpr moves per tile; that design needs hand-placed
-// assembly and is left for a later round.)
+// per kflop, K/V by LDS-DMA into a 3-deep ring, the softmax software-pipelined over 32-key units
+// inside the single wave per SIMD -- was built twice this round and passes the same tests, but does
+// not ship: plain C++ gives 557 TFLOP/s (hipcc parks accumulators in AGPRs and pays hundreds of
+// v_accvgpr moves per tile); with inline-asm MFMAs pinning O to AGPRs it reaches 645-750, and the
+// counters say why: 556 VALU instructions per tile and wave (~170 of them register shuffles) make it
+// VALU-issue bound.  It needs a hand-allocated instruction stream; left for a later round.)
 // LDS: K and V double-buffered separately (64 KiB).  K(t) and V(t-1) are read in steps 2t (A) and
 // 2t+1 (B); K(t+1) and V(t) are fetched to registers in step 2t and written in step 2t+1 into the
 // buffers of K(t-1) / V(t-2), both dead since step 2t-1.
@@ -583,6 +586,7 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
       }
   }
 }
+
 
 
 }  // namespace
