@@ -132,7 +132,7 @@ def test_attention_w8_structure(B, H, Lq, Lk):
     assert rel(out, ref) < 6e-3
 
 
-@pytest.mark.parametrize("force", ["SF_ATTN_W8", "SF_ATTN_W4", "SF_ATTN_R64"])
+@pytest.mark.parametrize("force", ["SF_ATTN_W8", "SF_ATTN_W4"])
 def test_attention_both_structures_small_and_spiky(force, monkeypatch):
     """Both kernels on the same ragged inputs incl. a late max spike (rescale branch) and Lk = 1."""
     monkeypatch.setenv(force, "1")
