@@ -318,8 +318,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(AttP p) {
 // counters say why: 556 VALU instructions per tile and wave (~170 of them register shuffles) make it
 // VALU-issue bound.  It needs a hand-allocated instruction stream; left for a later round.)
 // LDS: K and V double-buffered separately (64 KiB).  K(t) and V(t-1) are read in steps 2t (A) and
-// 2t+1 (B); K(t+1) and V(t) are fetched to registers in step 2t and written in step 2t+1 into the
-// buffers of K(t-1) / V(t-2), both dead since step 2t-1.
+// 2t+1 (B); K(t+1) and V(t) are requested by LDS-DMA in step 2t into the buffers of K(t-1) / V(t-2),
+// both dead since step 2t-1, and must have landed by the barrier that ends step 2t+1.
+// Measured shares at Lk = 32760 (compile-time ablation builds, -DSF_ABL_*): softmax 18 %, K/V
+// staging 10 % with register staging (VGPR + ds_write_b128) -> 7 % with LDS-DMA, the rest is the
+// MFMA + fragment-read skeleton.
 constexpr int QT8 = 256;
 constexpr int ATT8_THREADS = 512;
 constexpr int ATT8_LDS = 4 * TILE_B;  // K0 K1 V0 V1 = 64 KiB
@@ -354,36 +357,48 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
     for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
   }
 
-  // staging: 512 threads; a thread moves chunk (row = tid>>4 (+32), ch = tid&15) of a K and a V tile
-  const int st_row = tid >> 4, st_ch = tid & 15;
-  int st_lds[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) st_lds[i] = lds_off(st_row + 32 * i, st_ch);
+  // staging by LDS-DMA (`buffer_load_dwordx4 ... offen lds`, range-checked: rows past Lk read zero):
+  // a K or V tile is 16 pieces of 1 KiB (4 rows x 256 B); wave w issues pieces 2w, 2w+1 of each.
+  // Lane l of a piece lands at byte 16 l (lane-linear) = row l>>4, slot l&15, so it FETCHES chunk
+  // slot ^ swz(row): the swizzle sits on the source side.  Issued from inline asm: with the builtin
+  // hipcc puts `s_waitcnt vmcnt(0)` in front of every later ds_read (it cannot tell the buffers apart).
+  // No staging registers, no ds_write; completion = one vmcnt(0) before the barrier of the next step.
   const unsigned kv_bytes = (unsigned)(((long)(p.Lk - 1) * p.kv_stride + HD) * 2);
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, kv_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, kv_bytes, 0x00020000);
-  unsigned st_goff[2];
+  auto make_srd = [&](const bf16_t* base) {
+    const unsigned long long a64 = (unsigned long long)base;
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((unsigned)a64);
+    d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a64 >> 32) & 0xFFFFu);
+    d[2] = __builtin_amdgcn_readfirstlane(kv_bytes);
+    d[3] = 0x00020000u;
+    return d;
+  };
+  const u32x4 k_srd = make_srd(kbase), v_srd = make_srd(vbase);
+  unsigned dma_off[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) st_goff[i] = (unsigned)(((long)(st_row + 32 * i) * p.kv_stride + st_ch * 8) * 2);
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 4 + (lane >> 4);
+    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    dma_off[i] = (unsigned)(((long)row * p.kv_stride + chunk * 8) * 2);
+  }
   const unsigned tile_bytes = (unsigned)((long)KT * p.kv_stride * 2);
-  u32x4 kreg[2], vreg[2];
-  auto load_k = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, st_goff[i], (unsigned)t * tile_bytes, 0);
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  auto dma16 = [&](const u32x4& srd, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
   };
-  auto load_v = [&](int t) {
+  auto dma_k = [&](int t) {   // K(t) -> buffer t & 1
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((t & 1) * TILE_B + wave * 2048));
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)t * tile_bytes);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, st_goff[i], (unsigned)t * tile_bytes, 0);
+    for (int i = 0; i < 2; ++i) dma16(k_srd, dma_off[i], soff, base + i * 1024);
   };
-  auto write_k = [&](int t) {
-    char* kb = smem + (t & 1) * TILE_B;
+  auto dma_v = [&](int t) {   // V(t) -> buffer 2 + (t & 1)
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((2 + (t & 1)) * TILE_B + wave * 2048));
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)t * tile_bytes);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(kb + st_lds[i]) = kreg[i];
-  };
-  auto write_v = [&](int t) {
-    char* vb = smem + (2 + (t & 1)) * TILE_B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(vb + st_lds[i]) = vreg[i];
+    for (int i = 0; i < 2; ++i) dma16(v_srd, dma_off[i], soff, base + i * 1024);
   };
 
   int k_addr[8];
@@ -433,8 +448,14 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
+#ifdef SF_ABL_NOTR   // timing-only: one 16-byte row read instead of two transposed 8-byte reads
+        const bf16x8 w8 = *reinterpret_cast<const bf16x8*>(vb_lds + ks * 4096 + (v_lo[db] & ~15));
+        vlo[ks][db][0] = w8[0]; vlo[ks][db][1] = w8[1]; vlo[ks][db][2] = w8[2]; vlo[ks][db][3] = w8[3];
+        vhi[ks][db][0] = w8[4]; vhi[ks][db][1] = w8[5]; vhi[ks][db][2] = w8[6]; vhi[ks][db][3] = w8[7];
+#else
         vlo[ks][db] = lds_tr_read(vb_lds + ks * 4096 + v_lo[db]);
         vhi[ks][db] = lds_tr_read(vb_lds + ks * 4096 + v_hi[db]);
+#endif
       }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -479,6 +500,14 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
   };
   // ---- vector segment: online softmax of st -> pf
   auto seg_softmax = [&](int t) {
+#ifdef SF_ABL_NOSOFTMAX   // timing-only ablation build: convert S^T straight to bf16
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pf[2 * kb + (r >> 3)][r & 7] = (bf16_t)st[kb][r];
+    l_run += 1.f;
+    return;
+#endif
     if (tail && t == ntiles - 1) {
       asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch, not 32 selects per tile
       const int key0 = t * KT + 4 * hh;
@@ -521,54 +550,69 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
     l_run += lsum;
   };
 
-  load_k(0);
-  write_k(0);
+  // rows past Lk are never fetched (out of the descriptor's range): make sure they hold zeros and not
+  // whatever bit patterns a previous kernel left in LDS (0 * NaN = NaN in the P.V product)
+#pragma unroll
+  for (int i = 0; i < ATT8_LDS / (ATT8_THREADS * 16); ++i)
+    *reinterpret_cast<u32x4*>(smem + (i * ATT8_THREADS + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
+  dma_k(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
-  // Global steps g = 0 .. 2 ntiles + 1, one barrier after each but the last.  Every thread fetches
-  // K(tt+1), V(tt) in even steps g = 2 tt and publishes them in the following odd step.  The two
-  // halves run the same segments one step apart; written out per half so that every register's
+  // Global steps g = 0 .. 2 ntiles + 1, one barrier after each but the last.  In even steps g = 2 tt
+  // every wave requests K(tt+1) and V(tt) by LDS-DMA: their buffers (those of K(tt-1), V(tt-2)) were
+  // last read in step 2 tt - 1; the data is first read in step 2 tt + 2, so the DMA has two whole steps
+  // to land and is waited for (vmcnt(0), then the barrier) only at the end of the odd step 2 tt + 1.
+  // The halves run the same segments one step apart, written out per half so that every register's
   // live range is static (st: matrix -> vector of the same tile; pf: vector -> next matrix).
-  // Raw s_barrier + an LDS-only wait: __syncthreads() would also drain vmcnt(0), i.e. stall every
-  // step on the K/V prefetch issued a moment earlier (the loads are consumed a whole step later).
-  auto step_barrier = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  auto step_barrier = [&](bool dma_must_land) {
+    if (dma_must_land) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   auto fetch = [&](int tt) {
-    if (tt + 1 < ntiles) load_k(tt + 1);
-    if (tt < ntiles) load_v(tt);
-  };
-  auto publish = [&](int tt) {
-    if (tt + 1 < ntiles) write_k(tt + 1);
-    if (tt < ntiles) write_v(tt);
+#ifdef SF_ABL_NOSTAGE
+    return;
+#endif
+    if (tt + 1 < ntiles) dma_k(tt + 1);
+    if (tt < ntiles) dma_v(tt);
   };
   if (half == 0) {
-    for (int t = 0; t < ntiles; ++t) {
+    fetch(0);                         // g = 0
+    seg_qk(0);
+    step_barrier(false);
+    seg_softmax(0);                   // g = 1
+    step_barrier(true);
+    for (int t = 1; t < ntiles; ++t) {
       fetch(t);                       // g = 2t
-      if (t >= 1) seg_pv(t - 1);
+      seg_pv(t - 1);
       seg_qk(t);
-      step_barrier();
+      step_barrier(false);
       seg_softmax(t);                 // g = 2t + 1
-      publish(t);
-      step_barrier();
+      step_barrier(true);
     }
-    seg_pv(ntiles - 1);               // g = 2 ntiles
-    step_barrier();
+    seg_pv(ntiles - 1);   // g = 2 ntiles
+    step_barrier(false);
   } else {
     fetch(0);                         // g = 0
-    step_barrier();
-    for (int t = 0; t < ntiles; ++t) {
-      if (t >= 1) seg_pv(t - 1);      // g = 2t + 1
+    step_barrier(false);
+    seg_qk(0);     // g = 1
+    step_barrier(true);
+    fetch(1);                         // g = 2
+    seg_softmax(0);
+    step_barrier(false);
+    for (int t = 1; t < ntiles; ++t) {
+      seg_pv(t - 1);   // g = 2t + 1
       seg_qk(t);
-      publish(t);
-      step_barrier();
+      step_barrier(true);
       fetch(t + 1);                   // g = 2t + 2
       seg_softmax(t);
-      step_barrier();
+      step_barrier(false);
     }
-    seg_pv(ntiles - 1);               // g = 2 ntiles + 1
+    seg_pv(ntiles - 1);   // g = 2 ntiles + 1
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
