@@ -568,6 +568,9 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
   // The halves run the same segments one step apart, written out per half so that every register's
   // live range is static (st: matrix -> vector of the same tile; pf: vector -> next matrix).
   auto step_barrier = [&](bool dma_must_land) {
+#ifndef SF_ABL_EVENBAR
+    if (!dma_must_land) return;
+#endif
     if (dma_must_land) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
