@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 1
+#define SF_HIP_ABI_VERSION 2
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -40,7 +40,9 @@ enum sf_epilogue {
   SF_EPI_BIAS = 0,            /* y                                             */
   SF_EPI_BIAS_GELU = 1,       /* gelu_tanh(y)                                  */
   SF_EPI_BIAS_RESID = 2,      /* resid + y                                     */
-  SF_EPI_BIAS_GATE_RESID = 3  /* resid + y * (gate_mod[n] + gate_e0[group(m)][n]) */
+  SF_EPI_BIAS_GATE_RESID = 3, /* resid + y * (gate_mod[n] + gate_e0[group(m)][n]) */
+  SF_EPI_F32 = 4              /* raw fp32 accumulators, no bias: `out` is float*, ldo in floats
+                                 (attention logits of the VAE's single-head block) */
 };
 
 typedef struct sf_gemm_args {
@@ -205,6 +207,116 @@ typedef struct sf_forward_args {
 size_t sf_dit_workspace_bytes(const sf_model* model, int batch, int frames, int lat_h, int lat_w,
                               int groups);
 int sf_dit_forward(const sf_model* model, const sf_forward_args* args, void* stream);
+
+/* ==========================================================================================
+ * Wan VAE decode (latents -> pixels): WanVAEWrapper.decode_to_pixel -> WanVAE_.decode /
+ * cached_decode -> Decoder3d.forward (utils/wan_wrapper.py:95-117, wan/modules/vae.py:556-593,
+ * :423-472).  Activations are CHANNELS-LAST bf16 volumes [T][H][W][C]; the reference's
+ * `feat_cache` list (two cached input frames per causal convolution, vae.py:206-216) becomes two
+ * history frames kept physically in front of the new frames of each convolution's input buffer.
+ * ========================================================================================== */
+
+/* Implicit-GEMM convolution, fp32 accumulation on the matrix cores:
+ *   out[(t,h,w)][n] = bias[n] + sum_{dt,dh,dw,ci} x[t+dt+t_in_offset][(h+dh-kh/2)>>up][(w+dw-kw/2)>>up][ci]
+ *                                               * w[n][((dt*kh+dh)*kw+dw)*Cin + ci]
+ * with zero padding in h/w.  Replaces CausalConv3d (vae.py:17-38; kernel 3x3x3, (3,1,1) or 1x1x1),
+ * Resample's nearest-2x Upsample + Conv2d 3x3 (vae.py:77-83, :139-141; upsample = 1, kt = 1),
+ * the residual add of ResidualBlock (vae.py:221), the channel->frame interleave after the time
+ * convolution (vae.py:134-137) and the .float().clamp_(-1, 1) of decode_to_pixel (wan_wrapper.py:113). */
+enum sf_conv_epilogue {
+  SF_CONV_BIAS = 0,            /* bf16 out[row][n] = y                                            */
+  SF_CONV_BIAS_RESID = 1,      /* bf16 out[row][n] = y + resid[row][n]; resid may alias out       */
+  SF_CONV_BIAS_CLAMP_F32 = 2   /* float out_f32[t][n][h][w] = clamp(y, -1, 1) (planar, Cout small) */
+};
+
+typedef struct sf_conv_args {
+  const void* x;          /* [Tin][Hin][Win][Cin], Cin % 32 == 0                                   */
+  const void* w;          /* [Cout][ldw]: k = tap*Cin + ci, zero padded to ldw >= roundup(taps*Cin, 64) */
+  const void* bias;       /* [Cout]                                                                */
+  void* out;              /* rows of ldo channels; row = (out_frame_offset + t')*H*W + h*W + w     */
+  const void* resid;      /* same row indexing, ldr channels per row                               */
+  float* out_f32;         /* SF_CONV_BIAS_CLAMP_F32 only: [Tout][Cout][H][W]                       */
+  int32_t Tout, H, W;     /* output volume                                                         */
+  int32_t Hin, Win;       /* input frame size: (H, W), or (H/2, W/2) when upsample = 1             */
+  int32_t Cin, Cout;
+  int32_t kt, kh, kw;     /* 3 or 1 each; kh == kw                                                 */
+  int32_t upsample;       /* 1: read the input through a nearest-neighbour 2x upsampling           */
+  int32_t t_in_offset;    /* input frame of tap dt for output frame t is t + dt + t_in_offset      */
+  int32_t ldw, ldo, ldr;
+  int32_t out_frame_offset;
+  int32_t interleave_c;   /* > 0 (= Cout/2): channel n of output frame t goes to frame 2t + n/interleave_c,
+                             channel n % interleave_c (t' above)                                   */
+  int32_t epilogue;       /* enum sf_conv_epilogue */
+} sf_conv_args;
+
+int sf_conv_igemm(const sf_conv_args* args, void* stream);
+int sf_conv_pick_nt(int cout);   /* column tiles (of 16) per wave the launcher will use for Cout    */
+
+/* RMS_norm of the VAE (vae.py:41-56): out = x / max(||x||_2, 1e-12) * sqrt(C) * gamma over the C
+ * channels of each row, optionally followed by SiLU (the nn.SiLU after it in ResidualBlock / head,
+ * vae.py:190-196, :420-421).  x, out: [rows][C] contiguous, C % 8 == 0, C <= 512; in place allowed. */
+int sf_rmsnorm_silu_cl(const void* x, const void* gamma, void* out, int64_t rows, int C, int silu,
+                       void* stream);
+
+/* Row softmax of the single-head attention block (vae.py:252-257): p[r][c] = softmax_c(scale * s[r][c])
+ * for c < cols, 0 for cols <= c < cols_padded.  s float32 row stride lds, p bf16 row stride ldp. */
+int sf_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int rows, int cols,
+                    int cols_padded, float scale, void* stream);
+
+/* Latent frame -> input of decoder.conv1: un-scale (z * std + mean, vae.py:559-563), the 1x1x1
+ * conv2 (vae.py:564) and the layout change [z][h][w] -> [h][w][c_pad] (channels z..c_pad-1 zero). */
+int sf_vae_prepare_latent(const void* latent, const float* mean, const float* std, const void* conv2_w,
+                          const void* conv2_b, void* out, int z, int h, int w, int c_pad, void* stream);
+
+typedef struct sf_vae_conv {
+  const void* w;          /* repacked [cout][ldw] as sf_conv_args.w; NULL = layer absent           */
+  const void* bias;       /* [cout] */
+  int32_t cin, cout, kt, kh, kw, ldw;   /* cin already padded to a multiple of 32                  */
+} sf_vae_conv;
+
+typedef struct sf_vae_resblock {          /* ResidualBlock, vae.py:182-221 */
+  const void* gamma1;     /* residual.0.gamma [in_dim]  */
+  const void* gamma2;     /* residual.3.gamma [out_dim] */
+  sf_vae_conv conv1;      /* residual.2 */
+  sf_vae_conv conv2;      /* residual.6 */
+  sf_vae_conv shortcut;   /* 1x1x1, w = NULL when in_dim == out_dim */
+} sf_vae_resblock;
+
+#define SF_VAE_MAX_STAGES 4
+
+typedef struct sf_vae_model {             /* Decoder3d + conv2, vae.py:369-421, :503 */
+  int32_t z_dim;
+  int32_t n_stages;                       /* len(dim_mult) = 4                                      */
+  int32_t res_per_stage;                  /* num_res_blocks + 1 = 3                                 */
+  int32_t temporal_up[SF_VAE_MAX_STAGES]; /* stage i ends with upsample3d (1) / upsample2d (0); last stage: none */
+  const float* latent_mean;               /* float32 [z_dim] */
+  const float* latent_std;                /* float32 [z_dim] */
+  const void *conv2_w, *conv2_b;          /* [z][z], [z] */
+  sf_vae_conv conv1;                      /* decoder.conv1, cin padded to 32 */
+  sf_vae_resblock mid0, mid2;             /* decoder.middle.0 / .2 */
+  const void* attn_gamma;                 /* middle.1.norm.gamma [C]            */
+  const void *attn_qk_w, *attn_qk_b;      /* to_qkv rows [0, 2C): [2C][C], [2C] */
+  const void *attn_v_w, *attn_v_b;        /* to_qkv rows [2C, 3C)               */
+  const void *attn_proj_w, *attn_proj_b;  /* [C][C], [C] */
+  const sf_vae_resblock* res_host;        /* HOST array [n_stages * res_per_stage] */
+  sf_vae_conv time_conv[SF_VAE_MAX_STAGES];   /* per stage; w = NULL where absent  */
+  sf_vae_conv up_conv[SF_VAE_MAX_STAGES];     /* Resample.resample[1] (Conv2d 3x3) */
+  const void* head_gamma;                 /* decoder.head.0.gamma */
+  sf_vae_conv head_conv;                  /* decoder.head.2 (cout = 3) */
+} sf_vae_model;
+
+/* Per-stream persistent state = the input volumes (2 history frames + new frames) of every cached
+ * convolution; scratch = everything else, reusable by any stream that does not overlap in time. */
+size_t sf_vae_state_bytes(const sf_vae_model* model, int lat_h, int lat_w);
+size_t sf_vae_scratch_bytes(const sf_vae_model* model, int lat_h, int lat_w);
+/* WanVAE_.clear_cache (vae.py:610-617): zero every history. */
+int sf_vae_reset(const sf_vae_model* model, void* state, size_t state_bytes, int lat_h, int lat_w, void* stream);
+/* One iteration of the per-latent-frame loop of decode / cached_decode (vae.py:566-578):
+ * latent_frame [z][lat_h][lat_w] bf16 -> pixels [T][3][8 lat_h][8 lat_w] float32 in [-1, 1], T = 1 when
+ * `first_chunk` (the frame that follows a reset), else 4 (vae.py:109-111, :134-137). */
+int sf_vae_decode_frame(const sf_vae_model* model, void* state, size_t state_bytes, void* scratch,
+                        size_t scratch_bytes, const void* latent_frame, int lat_h, int lat_w,
+                        int first_chunk, float* pixels_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -14,9 +14,13 @@ from .wan_wrapper import WanDiffusionWrapper  # noqa: F401
 from .pipeline import CausalInferencePipeline  # noqa: F401
 from .harness import SyntheticTextEncoder, FixedTextEncoder, IdentityVAE  # noqa: F401
 from .concurrent import RolloutPool  # noqa: F401
+from .vae_weights import VaeShape, WAN_VAE, VAE_REDUCED, synth_vae_state_dict, vae_param_shapes  # noqa: F401
+from .vae import WanVAEWrapper, WanVAEDecoder, repack_conv  # noqa: F401
 from . import ops, _lib  # noqa: F401
 
 __all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict",
            "param_shapes", "merge_lora", "strip_prefix", "CachePlan", "plan_cache_update",
            "FlowMatchScheduler", "WanDiffusionWrapper", "CausalInferencePipeline",
-           "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "RolloutPool", "ops"]
+           "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "RolloutPool", "ops",
+           "VaeShape", "WAN_VAE", "VAE_REDUCED", "synth_vae_state_dict", "vae_param_shapes", "WanVAEWrapper",
+           "WanVAEDecoder", "repack_conv"]

@@ -13,10 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # epilogue codes (enum sf_epilogue)
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
+# enum sf_conv_epilogue
+CONV_BIAS, CONV_BIAS_RESID, CONV_BIAS_CLAMP_F32 = 0, 1, 2
+VAE_MAX_STAGES = 4
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 
 
@@ -73,6 +76,36 @@ class ForwardArgs(C.Structure):
     ]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("x", "w", "bias", "out", "resid", "out_f32")]
+        + [(n, C.c_int32) for n in ("Tout", "H", "W", "Hin", "Win", "Cin", "Cout", "kt", "kh", "kw", "upsample",
+                                    "t_in_offset", "ldw", "ldo", "ldr", "out_frame_offset", "interleave_c", "epilogue")]
+    )
+
+
+class VaeConv(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p)] + [(n, C.c_int32) for n in ("cin", "cout", "kt", "kh", "kw", "ldw")]
+
+
+class VaeResBlock(C.Structure):
+    _fields_ = [("gamma1", C.c_void_p), ("gamma2", C.c_void_p), ("conv1", VaeConv), ("conv2", VaeConv), ("shortcut", VaeConv)]
+
+
+class VaeModel(C.Structure):
+    _fields_ = [
+        ("z_dim", C.c_int32), ("n_stages", C.c_int32), ("res_per_stage", C.c_int32),
+        ("temporal_up", C.c_int32 * VAE_MAX_STAGES),
+        ("latent_mean", C.c_void_p), ("latent_std", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p),
+        ("conv1", VaeConv), ("mid0", VaeResBlock), ("mid2", VaeResBlock),
+        ("attn_gamma", C.c_void_p), ("attn_qk_w", C.c_void_p), ("attn_qk_b", C.c_void_p),
+        ("attn_v_w", C.c_void_p), ("attn_v_b", C.c_void_p), ("attn_proj_w", C.c_void_p), ("attn_proj_b", C.c_void_p),
+        ("res_host", C.POINTER(VaeResBlock)),
+        ("time_conv", VaeConv * VAE_MAX_STAGES), ("up_conv", VaeConv * VAE_MAX_STAGES),
+        ("head_gamma", C.c_void_p), ("head_conv", VaeConv),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/sf_hip.h declares
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -93,6 +126,15 @@ SIGNATURES = {
     "sf_add_noise": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _vp]),
     "sf_dit_workspace_bytes": (C.c_size_t, [C.POINTER(Model), _i, _i, _i, _i, _i]),
     "sf_dit_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ForwardArgs), _vp]),
+    "sf_conv_igemm": (C.c_int, [C.POINTER(ConvArgs), _vp]),
+    "sf_conv_pick_nt": (C.c_int, [_i]),
+    "sf_rmsnorm_silu_cl": (C.c_int, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "sf_softmax_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp]),
+    "sf_vae_prepare_latent": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_vae_state_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i]),
+    "sf_vae_scratch_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i]),
+    "sf_vae_reset": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _i, _i, _vp]),
+    "sf_vae_decode_frame": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _vp, _sz, _vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,328 @@
+// Implicit-GEMM convolution on channels-last bf16 volumes for gfx950 (MI355X).
+//
+// Replaces, on the VAE decode path, CausalConv3d (3x3x3, (3,1,1) and 1x1x1: wan/modules/vae.py:17-38),
+// the per-frame nn.Conv2d 3x3 of Resample INCLUDING the nearest-neighbour 2x upsampling in front of it
+// (vae.py:77-83, :139-141: the 4x larger tensor is never materialised), the bias add, the residual add
+// of ResidualBlock (vae.py:221), the channel->frame interleave after the time convolution
+// (vae.py:134-137) and the final float / clamp(-1, 1) of decode_to_pixel (utils/wan_wrapper.py:113).
+//
+//   out[(t,h,w)][n] = bias[n] + sum over taps (dt,dh,dw), ci of
+//                     x[t + dt + t_off][(h + dh - kh/2) >> up][(w + dw - kw/2) >> up][ci] * wk[n][tap*Cin + ci]
+//
+// i.e. a GEMM with M = Tout*H*W output positions, N = Cout, K = taps*Cin whose A operand is GATHERED:
+// K is walked in 32-channel slices (Cin % 32 == 0), two slices per 64-deep k-step, every slice lies
+// inside one tap, and a lane's 16-byte piece of an A row comes from the tap-shifted position or -- for
+// the zero padding in h/w, rows past M and the padding slice of an odd slice count -- from a page of
+// zeros.  Causality costs nothing here: the input volume holds the two history frames physically in
+// front of the new ones (the caller keeps them there), so t + dt never leaves the buffer.
+//
+// Everything after the gather is the GEMM of gemm_bf16.hip: 128 x (32 NT) output tile per 256-thread
+// workgroup, 4 waves as 2x2, 64 x (16 NT) per wave in 16x16x32 bf16 MFMAs, A and W tiles by LDS-DMA
+// into two stages, 128-byte LDS rows with the chunk swizzle c ^ ((r>>1)&7) applied on the source side
+// and on the ds_read_b128, operands swapped so that a lane owns 4 consecutive output channels.
+// NT in {1,2,3,4,6} covers Cout = 3 (head) ... 96, 192, 384, 768 without padding waste.
+#include <cstdlib>
+#include "sf_common.h"
+#include "../../include/sf_hip.h"
+
+namespace {
+
+constexpr int CBM = 128, CBK = 64;
+constexpr int CONV_THREADS = 256;
+constexpr int A_TILE_BYTES = CBM * CBK * 2;   // 16 KiB
+
+__device__ __attribute__((aligned(256))) unsigned char sf_zero_page[256];   // zero-initialised
+
+struct ConvP {
+  const bf16_t* x;
+  const bf16_t* w;
+  const bf16_t* bias;
+  bf16_t* out;
+  const bf16_t* resid;
+  float* out_f32;
+  int M, HW, H, W;
+  int Hin, Win, up;
+  int Cin, Cout, cpt, ntaps, khw, kw, ph, pw;
+  int t_off, nk, ldw, ldo, ldr, out_frame0, inter_c, Tout;
+  int tiles_m, tiles_n;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int NT, int EPI>
+__global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
+  constexpr int BN = 32 * NT;
+  constexpr int W_TILE_BYTES = BN * CBK * 2;
+  constexpr int STAGE = A_TILE_BYTES + W_TILE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware bijective remap, then row-tile-major order: consecutive workgroups of one XCD work on
+  // neighbouring output positions, whose gathered inputs overlap (taps) and share that XCD's L2
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  const int m0 = tm * CBM, n0 = tn * BN;
+
+  // ---- the four A pieces of this lane: row r, 16-byte chunk c (which fixes slice half and channel offset)
+  int pt[4], phh[4], pww[4], pcoff[4];
+  bool pvalid[4], phalf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int m = m0 + r;
+    pvalid[i] = m < p.M;
+    const int mm = min(m, p.M - 1);
+    const int t = mm / p.HW, hw = mm - t * p.HW;
+    const int h = hw / p.W;
+    pt[i] = t + p.t_off;
+    phh[i] = h - p.ph;
+    pww[i] = hw - h * p.W - p.pw;
+    phalf[i] = (c >> 2) != 0;
+    pcoff[i] = (c & 3) * 8;
+  }
+  const bf16_t* w_src[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int r = (wave * NT + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int n = min(n0 + r, p.Cout - 1);
+    w_src[j] = p.w + (long)n * p.ldw + c * 8;
+  }
+
+  // slice cursor of the NEXT stage to issue: slice 2 kt = (tap, cc), cc counting 32-channel groups
+  int tap = 0, cc = 0;
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE + wave * 4096;
+    int tap1 = tap, cc1 = cc + 1;
+    if (cc1 >= p.cpt) { cc1 -= p.cpt; ++tap1; }
+    // tap -> (dt, dh, dw): khw is 9 or 1, kw 3 or 1
+    int dt0, dh0, dw0, dt1, dh1, dw1;
+    if (p.khw == 9) {
+      dt0 = (tap * 57) >> 9; const int r0 = tap - 9 * dt0; dh0 = (r0 * 11) >> 5; dw0 = r0 - 3 * dh0;
+      dt1 = (tap1 * 57) >> 9; const int r1 = tap1 - 9 * dt1; dh1 = (r1 * 11) >> 5; dw1 = r1 - 3 * dh1;
+    } else {
+      dt0 = tap; dh0 = dw0 = 0; dt1 = tap1; dh1 = dw1 = 0;
+    }
+    const bool ok0 = tap < p.ntaps, ok1 = tap1 < p.ntaps;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int dt = phalf[i] ? dt1 : dt0, dh = phalf[i] ? dh1 : dh0, dw = phalf[i] ? dw1 : dw0;
+      const int ch = (phalf[i] ? cc1 : cc) * 32 + pcoff[i];
+      const int hh = phh[i] + dh, ww = pww[i] + dw;
+      const bool ok = pvalid[i] && (phalf[i] ? ok1 : ok0) && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
+      const long off = (((long)(pt[i] + dt) * p.Hin + (hh >> p.up)) * p.Win + (ww >> p.up)) * p.Cin + ch;
+      const void* src = ok ? (const void*)(p.x + off) : (const void*)sf_zero_page;
+      glds16(src, base + i * 1024);
+    }
+    char* wbase = smem + buf * STAGE + A_TILE_BYTES + wave * (NT * 1024);
+    const int k0 = kt * CBK;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) glds16(w_src[j] + k0, wbase + j * 1024);
+    // advance the cursor by two slices
+    cc += 2;
+    if (cc >= p.cpt) { cc -= p.cpt; ++tap; }
+    if (cc >= p.cpt) { cc -= p.cpt; ++tap; }
+  };
+
+  // ---- fragment read addresses
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int swz = (i16 >> 1) & 7;
+  const int x_row_off = (wr * 64 + i16) * 128;                              // + t*2048
+  const int w_row_off = A_TILE_BYTES + (wc * (16 * NT) + i16) * 128;       // + nt*2048
+  const int coff0 = ((0 + kq) ^ swz) << 4;
+  const int coff1 = ((4 + kq) ^ swz) << 4;
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < p.nk) stage(cur ^ 1, kt + 1);
+    const char* buf = smem + cur * STAGE;
+    bf16x8 xf0[4], xf1[4], wf0[NT], wf1[NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xf1[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wf1[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
+    // first sub-step's fragments up front, the second sub-step's reads under the first one's MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + NT, 0);
+#pragma unroll
+    for (int i = 0; i < 4 + NT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (4 + NT) > 0 ? (4 * NT) / (4 + NT) : 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);
+    __syncthreads();  // drains the in-flight LDS-DMA (vmcnt(0)) and orders the stage swap
+  }
+
+  // ---- epilogue: the lane holds out[m][n .. n+3] for (mt, nt); m = mrow + 16 mt, n = ncol + 16 nt
+  const int mrow = m0 + wr * 64 + (lane & 15);
+  const int ncol = n0 + wc * (16 * NT) + (lane >> 4) * 4;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = mrow + mt * 16;
+    if (m >= p.M) continue;
+    const int t = m / p.HW, hw = m - t * p.HW;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = ncol + nt * 16;
+      if (n >= p.Cout) continue;
+      float y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j];
+      if (EPI == SF_CONV_BIAS_CLAMP_F32) {
+        // Cout is tiny (3): per-element guards, planar float output [Tout][Cout][H][W]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n + j < p.Cout) {
+            const float v = y[j] + (float)p.bias[n + j];
+            p.out_f32[((long)t * p.Cout + n + j) * p.HW + hw] = fminf(fmaxf(v, -1.f), 1.f);
+          }
+        }
+        continue;
+      }
+      const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] += (float)b[j];
+      // channel -> frame interleave of the time convolution: channels [0,C) are frame 2t, [C,2C) frame 2t+1
+      int tf = t, nn = n;
+      if (p.inter_c > 0) {
+        const int sel = n >= p.inter_c ? 1 : 0;
+        tf = 2 * t + sel;
+        nn = n - sel * p.inter_c;
+      }
+      const long row = (long)(p.out_frame0 + tf) * p.HW + hw;
+      if (EPI == SF_CONV_BIAS_RESID) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + row * p.ldr + nn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
+      *reinterpret_cast<bf16x4*>(p.out + row * p.ldo + nn) = o;
+    }
+  }
+}
+
+template <int NT>
+int launch_nt(const ConvP& p, int epi, hipStream_t s) {
+  constexpr int LDS = 2 * (A_TILE_BYTES + 32 * NT * CBK * 2);
+  const dim3 grid(p.tiles_m * p.tiles_n), block(CONV_THREADS);
+  if (LDS > 64 * 1024) {   // above the default dynamic-LDS limit: opt in once per kernel
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<NT, SF_CONV_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<NT, SF_CONV_BIAS_RESID>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<NT, SF_CONV_BIAS_CLAMP_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      done = true;
+    }
+  }
+  switch (epi) {
+    case SF_CONV_BIAS: hipLaunchKernelGGL((conv_igemm_kernel<NT, SF_CONV_BIAS>), grid, block, LDS, s, p); break;
+    case SF_CONV_BIAS_RESID: hipLaunchKernelGGL((conv_igemm_kernel<NT, SF_CONV_BIAS_RESID>), grid, block, LDS, s, p); break;
+    case SF_CONV_BIAS_CLAMP_F32: hipLaunchKernelGGL((conv_igemm_kernel<NT, SF_CONV_BIAS_CLAMP_F32>), grid, block, LDS, s, p); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sf_conv_pick_nt(int cout) {
+  // the per-wave column count (16 NT) that pads Cout least; ties go to the larger tile
+  const int cand[5] = {6, 4, 3, 2, 1};
+  int best = 1;
+  long best_cost = -1;
+  for (int i = 0; i < 5; ++i) {
+    const int bn = 32 * cand[i];
+    const long cost = (long)((cout + bn - 1) / bn) * bn;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[i]; }
+  }
+  return best;
+}
+
+extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
+  SF_CHECK(a != nullptr, "sf_conv_igemm: null args");
+  SF_CHECK(a->x && a->w && a->bias, "sf_conv_igemm: null tensor");
+  SF_CHECK(a->Tout > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, "sf_conv_igemm: empty problem");
+  SF_CHECK(a->Cin % 32 == 0, "sf_conv_igemm: Cin=%d must be a multiple of 32 (pad the channels)", a->Cin);
+  SF_CHECK((a->kh == 3 && a->kw == 3) || (a->kh == 1 && a->kw == 1), "sf_conv_igemm: spatial taps must be 3x3 or 1x1");
+  SF_CHECK(a->kt == 1 || a->kt == 3, "sf_conv_igemm: kt must be 1 or 3");
+  SF_CHECK(a->upsample == 0 || a->upsample == 1, "sf_conv_igemm: upsample must be 0 or 1");
+  SF_CHECK(a->Hin == (a->upsample ? a->H / 2 : a->H) && a->Win == (a->upsample ? a->W / 2 : a->W) &&
+           (!a->upsample || (a->H % 2 == 0 && a->W % 2 == 0)), "sf_conv_igemm: input size %dx%d does not match output %dx%d", a->Hin, a->Win, a->H, a->W);
+  const int taps = a->kt * a->kh * a->kw;
+  const int slices = taps * (a->Cin / 32);
+  const int nk = (slices + 1) / 2;
+  SF_CHECK(a->ldw >= nk * 64 && a->ldw % 8 == 0, "sf_conv_igemm: weight row stride %d < padded K %d", a->ldw, nk * 64);
+  SF_CHECK((long)a->Tout * a->H * a->W < (1L << 31), "sf_conv_igemm: too many output positions");
+  SF_CHECK(a->t_in_offset >= 0, "sf_conv_igemm: negative input frame offset");
+  SF_CHECK(((uintptr_t)a->x % 16 == 0) && ((uintptr_t)a->w % 16 == 0) && ((uintptr_t)a->bias % 8 == 0), "sf_conv_igemm: misaligned tensor");
+  if (a->epilogue == SF_CONV_BIAS_CLAMP_F32) {
+    SF_CHECK(a->out_f32 != nullptr && a->interleave_c == 0, "sf_conv_igemm: float epilogue needs out_f32 and no interleave");
+  } else {
+    SF_CHECK(a->out != nullptr && a->ldo % 4 == 0 && a->Cout % 4 == 0, "sf_conv_igemm: bf16 output needs out, ldo %% 4 == 0, Cout %% 4 == 0");
+    SF_CHECK((uintptr_t)a->out % 8 == 0, "sf_conv_igemm: misaligned output");
+    SF_CHECK(a->interleave_c == 0 || (a->interleave_c * 2 == a->Cout && a->interleave_c % 4 == 0), "sf_conv_igemm: interleave_c must be Cout/2");
+    SF_CHECK(a->ldo >= (a->interleave_c ? a->interleave_c : a->Cout), "sf_conv_igemm: ldo too small");
+    if (a->epilogue == SF_CONV_BIAS_RESID)
+      SF_CHECK(a->resid != nullptr && a->ldr % 4 == 0 && a->ldr >= a->Cout && a->interleave_c == 0, "sf_conv_igemm: residual epilogue needs resid/ldr");
+  }
+  ConvP p;
+  p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = (const bf16_t*)a->bias;
+  p.out = (bf16_t*)a->out; p.resid = (const bf16_t*)a->resid; p.out_f32 = a->out_f32;
+  p.HW = a->H * a->W; p.M = a->Tout * p.HW; p.H = a->H; p.W = a->W; p.Tout = a->Tout;
+  p.Hin = a->Hin; p.Win = a->Win; p.up = a->upsample;
+  p.Cin = a->Cin; p.Cout = a->Cout; p.cpt = a->Cin / 32; p.ntaps = taps; p.khw = a->kh * a->kw; p.kw = a->kw;
+  p.ph = a->kh / 2; p.pw = a->kw / 2;
+  p.t_off = a->t_in_offset; p.nk = nk; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
+  p.out_frame0 = a->out_frame_offset; p.inter_c = a->interleave_c;
+  const int nt = sf_conv_pick_nt(a->Cout);
+  p.tiles_m = (p.M + CBM - 1) / CBM;
+  p.tiles_n = (a->Cout + 32 * nt - 1) / (32 * nt);
+  hipStream_t s = (hipStream_t)stream;
+  int rc = 0;
+  switch (nt) {
+    case 1: rc = launch_nt<1>(p, a->epilogue, s); break;
+    case 2: rc = launch_nt<2>(p, a->epilogue, s); break;
+    case 3: rc = launch_nt<3>(p, a->epilogue, s); break;
+    case 4: rc = launch_nt<4>(p, a->epilogue, s); break;
+    default: rc = launch_nt<6>(p, a->epilogue, s); break;
+  }
+  SF_CHECK(rc == 0, "sf_conv_igemm: unknown epilogue %d", a->epilogue);
+  SF_HIP_LAUNCH_CHECK("sf_conv_igemm");
+  return 0;
+}

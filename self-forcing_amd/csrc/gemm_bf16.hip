@@ -60,6 +60,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
     for (int nt = 0; nt < 4; ++nt) {
       const int n = ncol + nt * 16;
       if (n >= p.N) continue;
+      if (EPI == SF_EPI_F32) {   // raw accumulators (attention logits): `out` is float*, ldo in floats
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = acc[mt][nt];
+        continue;
+      }
       float y[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j];
@@ -236,6 +240,10 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
     case SF_EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS_GELU>, grid, block, GEMM_LDS, s, p); break;
     case SF_EPI_BIAS_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS_RESID>, grid, block, GEMM_LDS, s, p); break;
     case SF_EPI_BIAS_GATE_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS_GATE_RESID>, grid, block, GEMM_LDS, s, p); break;
+    case SF_EPI_F32:
+      SF_CHECK((uintptr_t)a->out % 16 == 0, "sf_gemm_bf16: fp32 output must be 16-byte aligned");
+      hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_F32>, grid, block, GEMM_LDS, s, p);
+      break;
     default: SF_CHECK(false, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
   }
   SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");

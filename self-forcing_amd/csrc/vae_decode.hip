@@ -1,0 +1,282 @@
+// One iteration of the Wan VAE's per-latent-frame decode loop as a single host call that enqueues
+// every kernel on the caller's stream: WanVAE_.decode / cached_decode (wan/modules/vae.py:556-593) ->
+// Decoder3d.forward with feat_cache (vae.py:423-472).
+//
+// Host-side only (no kernels here).  The reference threads a list of 32 cache tensors and an index
+// counter through the modules and re-concatenates [cache, x] in front of every convolution; here each
+// cached convolution owns ONE input volume [2 + T][H][W][C] in the per-stream state: its producer (the
+// RMS-norm/SiLU kernel, or the previous block's epilogue) writes the T new frames behind the two
+// history frames, the convolution gathers its temporal taps from frames t, t+1, t+2, and the last two
+// frames are then copied to the front (the cache update of vae.py:206-216; for T = 1 that is the
+// "borrow the last frame of the previous cache" branch).  A zeroed history IS the reference's zero
+// padding of the first chunk, so there is no first-chunk special case in the convolutions.  The two
+// quirks of Resample's bookkeeping (vae.py:104-132) are kept: the first chunk after a reset skips the
+// time convolution (one output frame), and its features never enter that convolution's history.
+#include <cmath>
+#include <cstring>
+#include "sf_common.h"
+#include "../../include/sf_hip.h"
+
+namespace {
+
+struct Carve {
+  char* base;
+  size_t off;
+  explicit Carve(void* p) : base((char*)p), off(0) {}
+  char* take(size_t bytes) {
+    char* r = base ? base + off : nullptr;
+    off += (bytes + 255) & ~(size_t)255;
+    return r;
+  }
+};
+
+struct BlockBufs { char *a1, *a2; };
+
+struct Plan {
+  int n_stages, rps;
+  int H[SF_VAE_MAX_STAGES], W[SF_VAE_MAX_STAGES], Tmax[SF_VAE_MAX_STAGES];
+  // state
+  char* c1_in;
+  BlockBufs mid0, mid2;
+  BlockBufs blk[SF_VAE_MAX_STAGES * 8];
+  char* tc[SF_VAE_MAX_STAGES];
+  char* head_in;
+  size_t state_total;
+  // scratch
+  char *xi[SF_VAE_MAX_STAGES], *x[SF_VAE_MAX_STAGES], *ty[SF_VAE_MAX_STAGES];
+  char *y1, *sc;
+  char *att_xn, *att_qk, *att_vt, *att_s, *att_p, *att_o;
+  int att_npad;
+  size_t scratch_total;
+};
+
+inline size_t vol(int T, int H, int W, int C) { return (size_t)T * H * W * C * 2; }
+
+const sf_vae_resblock& res_at(const sf_vae_model* m, int stage, int j) { return m->res_host[stage * m->res_per_stage + j]; }
+
+Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w) {
+  Plan p;
+  memset(&p, 0, sizeof(p));
+  p.n_stages = m->n_stages;
+  p.rps = m->res_per_stage;
+  int T = 1;
+  for (int i = 0; i < m->n_stages; ++i) {
+    p.H[i] = h << i;
+    p.W[i] = w << i;
+    p.Tmax[i] = T;
+    if (i + 1 < m->n_stages && m->temporal_up[i]) T *= 2;
+  }
+  Carve st(state);
+  p.c1_in = st.take(vol(3, h, w, m->conv1.cin));
+  const int C0 = m->conv1.cout;
+  p.mid0.a1 = st.take(vol(3, h, w, C0)); p.mid0.a2 = st.take(vol(3, h, w, C0));
+  p.mid2.a1 = st.take(vol(3, h, w, C0)); p.mid2.a2 = st.take(vol(3, h, w, C0));
+  for (int i = 0; i < m->n_stages; ++i) {
+    for (int j = 0; j < m->res_per_stage; ++j) {
+      const sf_vae_resblock& r = res_at(m, i, j);
+      BlockBufs& b = p.blk[i * m->res_per_stage + j];
+      b.a1 = st.take(vol(2 + p.Tmax[i], p.H[i], p.W[i], r.conv1.cin));
+      b.a2 = st.take(vol(2 + p.Tmax[i], p.H[i], p.W[i], r.conv2.cin));
+    }
+    p.tc[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? st.take(vol(2 + p.Tmax[i], p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
+  }
+  const int L = m->n_stages - 1;
+  p.head_in = st.take(vol(2 + p.Tmax[L], p.H[L], p.W[L], m->head_conv.cin));
+  p.state_total = st.off;
+
+  Carve sc(scratch);
+  size_t y1_max = vol(1, h, w, C0), sc_max = 256;
+  for (int i = 0; i < m->n_stages; ++i) {
+    const int cin = res_at(m, i, 0).conv1.cin, cout = res_at(m, i, 0).conv1.cout;
+    p.xi[i] = sc.take(vol(p.Tmax[i], p.H[i], p.W[i], i == 0 ? C0 : cin));
+    p.x[i] = sc.take(vol(p.Tmax[i], p.H[i], p.W[i], cout));
+    p.ty[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? sc.take(vol(2 * p.Tmax[i], p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
+    for (int j = 0; j < m->res_per_stage; ++j) {
+      const sf_vae_resblock& r = res_at(m, i, j);
+      const size_t v = vol(p.Tmax[i], p.H[i], p.W[i], r.conv1.cout);
+      if (v > y1_max) y1_max = v;
+      if (r.shortcut.w && v > sc_max) sc_max = v;
+    }
+  }
+  p.y1 = sc.take(y1_max);
+  p.sc = sc.take(sc_max);
+  const int n = h * w;
+  p.att_npad = (n + 63) & ~63;
+  p.att_xn = sc.take((size_t)n * C0 * 2);
+  p.att_qk = sc.take((size_t)n * 2 * C0 * 2);
+  p.att_vt = sc.take((size_t)C0 * p.att_npad * 2);
+  p.att_s = sc.take((size_t)n * p.att_npad * 4);
+  p.att_p = sc.take((size_t)n * p.att_npad * 2);
+  p.att_o = sc.take((size_t)n * C0 * 2);
+  p.scratch_total = sc.off;
+  return p;
+}
+
+int check_model(const sf_vae_model* m, int h, int w) {
+  SF_CHECK(m != nullptr, "sf_vae: null model");
+  SF_CHECK(m->n_stages >= 1 && m->n_stages <= SF_VAE_MAX_STAGES && m->res_per_stage >= 1 && m->res_per_stage <= 8, "sf_vae: bad stage counts");
+  SF_CHECK(m->res_host && m->conv1.w && m->head_conv.w && m->latent_mean && m->latent_std && m->conv2_w && m->conv2_b, "sf_vae: model has null weights");
+  SF_CHECK(h > 0 && w > 0 && (h * w) % 4 == 0, "sf_vae: latent size %dx%d (h*w must be a multiple of 4)", h, w);
+  SF_CHECK(m->conv1.cout % 64 == 0, "sf_vae: decoder width %d must be a multiple of 64 (attention block GEMMs)", m->conv1.cout);
+  SF_CHECK(m->z_dim > 0 && m->z_dim <= 32 && m->conv1.cin >= m->z_dim, "sf_vae: bad z_dim");
+  return 0;
+}
+
+#define SF_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+int conv(const sf_vae_conv& c, const void* x, int Tout, int H, int W, int upsample, int t_off, void* out, int ldo, int out_frame0,
+         int interleave_c, int epi, const void* resid, int ldr, float* out_f32, void* stream) {
+  sf_conv_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = c.w; a.bias = c.bias; a.out = out; a.resid = resid; a.out_f32 = out_f32;
+  a.Tout = Tout; a.H = H; a.W = W; a.Hin = upsample ? H / 2 : H; a.Win = upsample ? W / 2 : W;
+  a.Cin = c.cin; a.Cout = c.cout; a.kt = c.kt; a.kh = c.kh; a.kw = c.kw; a.upsample = upsample; a.t_in_offset = t_off;
+  a.ldw = c.ldw; a.ldo = ldo; a.ldr = ldr; a.out_frame_offset = out_frame0; a.interleave_c = interleave_c; a.epilogue = epi;
+  return sf_conv_igemm(&a, stream);
+}
+
+int gemm(const void* a, int lda, const void* w, int ldw, const void* bias, void* out, int ldo, int M, int N, int K, int epi,
+         const void* resid, int ldr, void* stream) {
+  sf_gemm_args g;
+  memset(&g, 0, sizeof(g));
+  g.a = a; g.w = w; g.bias = bias; g.out = out; g.resid = resid; g.rows_per_group = 1;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldr = ldr; g.epilogue = epi;
+  return sf_gemm_bf16(&g, stream);
+}
+
+// the cache update: the last two of the 2 + T frames move to the front
+int shift_history(char* buf, int T, size_t frame_bytes, hipStream_t s) {
+  for (int k = 0; k < 2; ++k) {
+    hipError_t e = hipMemcpyAsync(buf + k * frame_bytes, buf + (size_t)(T + k) * frame_bytes, frame_bytes, hipMemcpyDeviceToDevice, s);
+    SF_CHECK(e == hipSuccess, "sf_vae: history copy failed: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+// ResidualBlock.forward (vae.py:202-221) on T frames of H x W
+int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, int T, int H, int W, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long rows = (long)T * H * W;
+  const int cin = r.conv1.cin, cout = r.conv1.cout;
+  const size_t f1 = vol(1, H, W, cin), f2 = vol(1, H, W, cout);
+  SF_TRY(sf_rmsnorm_silu_cl(x_in, r.gamma1, b.a1 + 2 * f1, rows, cin, 1, stream));
+  SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, 0, p.y1, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+  SF_TRY(shift_history(b.a1, T, f1, s));
+  SF_TRY(sf_rmsnorm_silu_cl(p.y1, r.gamma2, b.a2 + 2 * f2, rows, cout, 1, stream));
+  const char* resid = x_in;
+  if (r.shortcut.w) {
+    SF_TRY(conv(r.shortcut, x_in, T, H, W, 0, 0, p.sc, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+    resid = p.sc;
+  }
+  SF_TRY(conv(r.conv2, b.a2, T, H, W, 0, 0, out, cout, 0, 0, SF_CONV_BIAS_RESID, resid, cout, nullptr, stream));
+  SF_TRY(shift_history(b.a2, T, f2, s));
+  return 0;
+}
+
+// AttentionBlock.forward (vae.py:241-264) on one frame of n = h*w positions, in place on x [n][C]
+int attention_block(const sf_vae_model* m, const Plan& p, char* x, int n, int C, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int np = p.att_npad;
+  SF_TRY(sf_rmsnorm_silu_cl(x, m->attn_gamma, p.att_xn, n, C, 0, stream));
+  SF_TRY(gemm(p.att_xn, C, m->attn_qk_w, C, m->attn_qk_b, p.att_qk, 2 * C, n, 2 * C, C, SF_EPI_BIAS, nullptr, 0, stream));
+  // V^T [C][np] = Wv . xn^T straight from the projection (no transpose pass); its bias is added after
+  // the P.V product instead (softmax rows sum to one), the padded key columns stay zero
+  hipError_t e = hipMemsetAsync(p.att_vt, 0, (size_t)C * np * 2, s);
+  SF_CHECK(e == hipSuccess, "sf_vae: memset failed: %s", hipGetErrorString(e));
+  SF_TRY(gemm(m->attn_v_w, C, p.att_xn, C, nullptr, p.att_vt, np, C, n, C, SF_EPI_BIAS, nullptr, 0, stream));
+  SF_TRY(gemm(p.att_qk, 2 * C, p.att_qk + (size_t)C * 2, 2 * C, nullptr, p.att_s, np, n, n, C, SF_EPI_F32, nullptr, 0, stream));
+  SF_TRY(sf_softmax_rows((const float*)p.att_s, np, p.att_p, np, n, n, np, 1.0f / sqrtf((float)C), stream));
+  SF_TRY(gemm(p.att_p, np, p.att_vt, np, m->attn_v_b, p.att_o, C, n, C, np, SF_EPI_BIAS, nullptr, 0, stream));
+  SF_TRY(gemm(p.att_o, C, m->attn_proj_w, C, m->attn_proj_b, x, C, n, C, C, SF_EPI_BIAS_RESID, x, C, stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t sf_vae_state_bytes(const sf_vae_model* m, int h, int w) {
+  if (check_model(m, h, w) != 0) return 0;
+  return make_plan(m, nullptr, nullptr, h, w).state_total;
+}
+
+extern "C" size_t sf_vae_scratch_bytes(const sf_vae_model* m, int h, int w) {
+  if (check_model(m, h, w) != 0) return 0;
+  return make_plan(m, nullptr, nullptr, h, w).scratch_total;
+}
+
+extern "C" int sf_vae_reset(const sf_vae_model* m, void* state, size_t state_bytes, int h, int w, void* stream) {
+  SF_TRY(check_model(m, h, w));
+  const Plan p = make_plan(m, nullptr, nullptr, h, w);
+  SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_reset: state too small (%zu < %zu)", state_bytes, p.state_total);
+  hipError_t e = hipMemsetAsync(state, 0, p.state_total, (hipStream_t)stream);
+  SF_CHECK(e == hipSuccess, "sf_vae_reset: memset failed: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                                   const void* latent_frame, int h, int w, int first_chunk, float* pixels_out, void* stream) {
+  SF_TRY(check_model(m, h, w));
+  SF_CHECK(latent_frame && pixels_out, "sf_vae_decode_frame: null tensor");
+  const Plan p = make_plan(m, state, scratch, h, w);
+  SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_decode_frame: state too small (%zu < %zu)", state_bytes, p.state_total);
+  SF_CHECK(scratch && scratch_bytes >= p.scratch_total, "sf_vae_decode_frame: scratch too small (%zu < %zu)", scratch_bytes, p.scratch_total);
+  hipStream_t s = (hipStream_t)stream;
+  const int C0 = m->conv1.cout;
+
+  // un-scale + conv2 (1x1x1) -> the new frame of decoder.conv1's input volume; conv1 (vae.py:425-438)
+  const size_t f_in = vol(1, h, w, m->conv1.cin);
+  SF_TRY(sf_vae_prepare_latent(latent_frame, m->latent_mean, m->latent_std, m->conv2_w, m->conv2_b, p.c1_in + 2 * f_in, m->z_dim, h, w,
+                               m->conv1.cin, stream));
+  SF_TRY(conv(m->conv1, p.c1_in, 1, h, w, 0, 0, p.xi[0], C0, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+  SF_TRY(shift_history(p.c1_in, 1, f_in, s));
+
+  // middle (vae.py:441-445): res, attention, res -- all on the one latent-rate frame
+  SF_CHECK(res_at(m, 0, 0).conv1.cin == C0 && res_at(m, 0, 0).conv1.cout == C0, "sf_vae_decode_frame: stage 0 must keep the decoder width");
+  SF_TRY(resblock(m->mid0, p.mid0, p, p.xi[0], p.x[0], 1, h, w, stream));
+  SF_TRY(attention_block(m, p, p.x[0], h * w, C0, stream));
+  SF_TRY(resblock(m->mid2, p.mid2, p, p.x[0], p.x[0], 1, h, w, stream));
+
+  // upsample stages (vae.py:448-452)
+  int T = 1;
+  const char* cur = p.x[0];   // the stage's running activation
+  for (int i = 0; i < m->n_stages; ++i) {
+    const int H = p.H[i], W = p.W[i];
+    const bool has_up = i + 1 < m->n_stages;
+    const bool has_tc = has_up && m->time_conv[i].w != nullptr;
+    for (int j = 0; j < m->res_per_stage; ++j) {
+      const sf_vae_resblock& r = res_at(m, i, j);
+      char* out = p.x[i];
+      if (j == m->res_per_stage - 1 && has_tc) out = p.tc[i] + 2 * vol(1, H, W, m->time_conv[i].cin);   // feeds the time conv
+      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, T, H, W, stream));
+      cur = out;
+    }
+    if (!has_up) break;
+    const sf_vae_conv& uc = m->up_conv[i];
+    const char* up_in = cur;
+    int Tn = T;
+    if (has_tc && !first_chunk) {
+      // Resample 'upsample3d' (vae.py:112-137): (3,1,1) causal conv C -> 2C, channel halves -> frames 2t, 2t+1
+      const sf_vae_conv& tcv = m->time_conv[i];
+      SF_CHECK(tcv.cout == 2 * tcv.cin, "sf_vae_decode_frame: time conv must double the channels");
+      SF_TRY(conv(tcv, p.tc[i], T, H, W, 0, 0, p.ty[i], tcv.cin, 0, tcv.cin, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+      SF_TRY(shift_history(p.tc[i], T, vol(1, H, W, tcv.cin), s));
+      up_in = p.ty[i];
+      Tn = 2 * T;
+    }
+    // nearest 2x + Conv2d 3x3 per frame (vae.py:139-141), fused
+    SF_TRY(conv(uc, up_in, Tn, 2 * H, 2 * W, 1, 0, p.xi[i + 1], uc.cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+    cur = p.xi[i + 1];
+    T = Tn;
+  }
+
+  // head (vae.py:455-471): RMS-norm, SiLU, causal conv to 3 channels; float, clamp
+  const int L = m->n_stages - 1;
+  const int Ch = m->head_conv.cin;
+  SF_TRY(sf_rmsnorm_silu_cl(cur, m->head_gamma, p.head_in + 2 * vol(1, p.H[L], p.W[L], Ch), (long)T * p.H[L] * p.W[L], Ch, 1, stream));
+  SF_TRY(conv(m->head_conv, p.head_in, T, p.H[L], p.W[L], 0, 0, nullptr, 0, 0, 0, SF_CONV_BIAS_CLAMP_F32, nullptr, 0, pixels_out, stream));
+  SF_TRY(shift_history(p.head_in, T, vol(1, p.H[L], p.W[L], Ch), s));
+  return 0;
+}

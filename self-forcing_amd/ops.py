@@ -11,11 +11,12 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, EPI_BIAS, EPI_BIAS_GATE_RESID, EPI_BIAS_GELU,
-                   EPI_BIAS_RESID, GemmArgs, check, lib)
+from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, CONV_BIAS, CONV_BIAS_CLAMP_F32, CONV_BIAS_RESID, EPI_BIAS,
+                   EPI_BIAS_GATE_RESID, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_F32, ConvArgs, GemmArgs, check, lib)
 
 Tensor = torch.Tensor
-_EPI = {"bias": EPI_BIAS, "gelu": EPI_BIAS_GELU, "resid": EPI_BIAS_RESID, "gate_resid": EPI_BIAS_GATE_RESID}
+_EPI = {"bias": EPI_BIAS, "gelu": EPI_BIAS_GELU, "resid": EPI_BIAS_RESID, "gate_resid": EPI_BIAS_GATE_RESID,
+        "f32": EPI_F32}
 _ACT = {None: ACT_NONE, "none": ACT_NONE, "silu": ACT_SILU, "gelu": ACT_GELU}
 
 
@@ -59,9 +60,15 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: str = "b
     N = w.shape[0]
     if w.shape[1] != K:
         raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
-    if out is None:
-        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
-    _rows(out, "out")
+    if epilogue == "f32":   # raw fp32 accumulators (no bias)
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
+            raise ValueError("gemm: the f32 epilogue needs a float32 2-D output with contiguous rows")
+    else:
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+        _rows(out, "out")
     g = GemmArgs()
     g.a, g.w, g.bias, g.out = a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr()
     g.M, g.N, g.K = M, N, K
@@ -204,4 +211,67 @@ def add_noise(x0: Tensor, eps: Tensor, timestep: Tensor, sigmas: Tensor, timeste
     out = torch.empty_like(eps)
     check(lib().sf_add_noise(x0.data_ptr(), eps.data_ptr(), tt.data_ptr(), is64, sigmas.data_ptr(), timesteps.data_ptr(),
                              sigmas.numel(), out.data_ptr(), n, inner, stream_handle()), "sf_add_noise")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# VAE decode kernels (channels-last bf16 volumes)
+def conv_igemm(x: Tensor, w_packed: Tensor, bias: Tensor, kernel, t_out: int, upsample: bool = False,
+               t_in_offset: int = 0, resid: Optional[Tensor] = None, interleave: bool = False,
+               clamp_f32: bool = False, cin: Optional[int] = None) -> Tensor:
+    """Implicit-GEMM convolution (sf_conv_igemm).  x [Tin, Hin, Win, Cin] channels-last with the history
+    frames in front; w_packed from `vae.repack_conv`; kernel = (kt, kh, kw).  Returns [Tout, H, W, Cout]
+    bf16 -- [2 Tout, H, W, Cout/2] with `interleave` -- or float32 [Tout, Cout, H, W] with `clamp_f32`."""
+    _bf16(x, "x"), _bf16(w_packed, "w_packed"), _bf16(bias, "bias")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("conv_igemm: x must be a contiguous [T, H, W, C] volume")
+    tin, hin, win, c = x.shape
+    kt, kh, kw = kernel
+    cout = w_packed.shape[0]
+    H, W = (2 * hin, 2 * win) if upsample else (hin, win)
+    if t_out + (kt - 1) + t_in_offset > tin:
+        raise ValueError(f"conv_igemm: {tin} input frames do not cover {t_out} output frames (kt={kt}, offset={t_in_offset})")
+    a = ConvArgs()
+    a.x, a.w, a.bias = x.data_ptr(), w_packed.data_ptr(), bias.data_ptr()
+    a.Tout, a.H, a.W, a.Hin, a.Win = t_out, H, W, hin, win
+    a.Cin, a.Cout, a.kt, a.kh, a.kw = cin or c, cout, kt, kh, kw
+    a.upsample, a.t_in_offset, a.ldw = int(upsample), t_in_offset, w_packed.stride(0)
+    if clamp_f32:
+        out = torch.empty(t_out, cout, H, W, dtype=torch.float32, device=x.device)
+        a.out_f32, a.epilogue = out.data_ptr(), CONV_BIAS_CLAMP_F32
+    else:
+        co = cout // 2 if interleave else cout
+        out = torch.empty(2 * t_out if interleave else t_out, H, W, co, dtype=torch.bfloat16, device=x.device)
+        a.out, a.ldo, a.epilogue = out.data_ptr(), co, CONV_BIAS
+        a.interleave_c = co if interleave else 0
+        if resid is not None:
+            _bf16(resid, "resid")
+            if tuple(resid.shape) != tuple(out.shape) or not resid.is_contiguous():
+                raise ValueError("conv_igemm: resid must match the output volume")
+            a.resid, a.ldr, a.epilogue = resid.data_ptr(), cout, CONV_BIAS_RESID
+    check(lib().sf_conv_igemm(a, stream_handle()), "sf_conv_igemm")
+    return out
+
+
+def rmsnorm_silu_cl(x: Tensor, gamma: Tensor, silu: bool = True) -> Tensor:
+    """VAE RMS_norm over the last (channel) dim of a contiguous channels-last tensor, optional SiLU."""
+    _bf16(x, "x"), _bf16(gamma, "gamma")
+    if not x.is_contiguous():
+        raise ValueError("rmsnorm_silu_cl: x must be contiguous")
+    out = torch.empty_like(x)
+    c = x.shape[-1]
+    check(lib().sf_rmsnorm_silu_cl(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel() // c, c, int(silu), stream_handle()),
+          "sf_rmsnorm_silu_cl")
+    return out
+
+
+def softmax_rows(s: Tensor, scale: float, cols_padded: Optional[int] = None) -> Tensor:
+    """bf16 softmax(scale * s) over the rows of a float32 matrix; columns up to cols_padded are zero."""
+    if s.dtype != torch.float32 or s.dim() != 2 or s.stride(1) != 1 or not s.is_cuda:
+        raise ValueError("softmax_rows: expected a CUDA float32 matrix with contiguous rows")
+    rows, cols = s.shape
+    cp = cols_padded or cols
+    out = torch.empty(rows, cp, dtype=torch.bfloat16, device=s.device)
+    check(lib().sf_softmax_rows(s.data_ptr(), s.stride(0), out.data_ptr(), cp, rows, cols, cp, float(scale), stream_handle()),
+          "sf_softmax_rows")
     return out
