@@ -154,3 +154,35 @@ def synth_vae_state_dict(s: VaeShape, seed: int = 0, dtype=torch.bfloat16) -> Di
             t = torch.empty(shape).uniform_(-a, a, generator=g)
         sd[name] = t.to(dtype)
     return sd
+
+
+def vae_decode_flops(s: VaeShape, lat_h: int, lat_w: int, latent_frames: int) -> float:
+    """Algorithmic FLOPs (multiply-add = 2) of `decode` on `latent_frames` latent frames: every
+    convolution at its true channel counts (2 * taps * Cin * Cout per output position), the attention
+    block's projections and its two token-by-token products.  The first latent frame runs every stage
+    at one frame (no time convolution); later frames double the frame count after each upsample3d."""
+    middle, ups = decoder_layout(s)
+    d0 = s.dims[0]
+
+    def one(first: bool) -> float:
+        h, w, t = lat_h, lat_w, 1
+        pos = h * w
+        fl = 2.0 * s.z_dim * s.z_dim * pos + 2.0 * 27 * s.z_dim * d0 * pos               # conv2, decoder.conv1
+        fl += 2 * (2.0 * 27 * d0 * d0 * pos * 2)                                             # two middle res blocks
+        fl += 2.0 * d0 * 3 * d0 * pos + 2.0 * d0 * d0 * pos + 4.0 * pos * pos * d0           # attention block
+        for spec in ups:
+            pos = t * h * w
+            if isinstance(spec, ResBlockSpec):
+                fl += 2.0 * 27 * spec.in_dim * spec.out_dim * pos + 2.0 * 27 * spec.out_dim * spec.out_dim * pos
+                if spec.in_dim != spec.out_dim:
+                    fl += 2.0 * spec.in_dim * spec.out_dim * pos
+            else:
+                if spec.mode == "upsample3d" and not first:
+                    fl += 2.0 * 3 * spec.dim * 2 * spec.dim * pos
+                    t *= 2
+                h, w = 2 * h, 2 * w
+                fl += 2.0 * 9 * spec.dim * (spec.dim // 2) * t * h * w
+        fl += 2.0 * 27 * s.dims[-1] * 3 * t * h * w                                          # head
+        return fl
+
+    return one(True) + (latent_frames - 1) * one(False)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Kernel micro-benchmarks at the S1 shapes (for rocprofv3 --pmc passes and A/B timing):
-self-attention N=4680 x Lk, and the four GEMM shapes of one DiT block."""
+self-attention N=4680 x Lk, the four GEMM shapes of one DiT block, and (--what vae) the VAE decode of
+one 21-frame 60x104 latent clip."""
 import argparse
 import os
 import sys
@@ -30,6 +31,7 @@ def main():
     ap.add_argument("--n", type=int, default=4680)
     ap.add_argument("--lk", default="4680,18720,32760")
     ap.add_argument("--heads", type=int, default=12)
+    ap.add_argument("--vae-frames", type=int, default=21)
     a = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(0)
@@ -42,6 +44,8 @@ def main():
             ms = timeit(lambda: ops.attention(q, k, v), a.iters)
             fl = 4.0 * C * a.n * lk
             print(f"attention N={a.n} Lk={lk} H={a.heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    if "vae" in a.what:
+        bench_vae(a.vae_frames, max(1, a.iters // 5))
     if "gemm" in a.what:
         for (N, K, epi) in [(3 * C, C, "bias"), (C, C, "resid"), (8960 if C == 1536 else 13824, C, "gelu"),
                             (C, 8960 if C == 1536 else 13824, "resid")]:
@@ -53,6 +57,19 @@ def main():
             kw = {"resid": r} if epi == "resid" else {}
             ms = timeit(lambda: ops.gemm(x, w, b, epilogue=epi, out=o, **kw), a.iters)
             print(f"gemm M={a.n} N={N} K={K} {epi:6s}: {ms * 1e3:8.1f} us  {2.0 * a.n * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+
+
+def bench_vae(frames, iters):
+    import self_forcing_amd as sfa
+    from self_forcing_amd import vae_weights as vw
+    dev = "cuda:0"
+    vae = sfa.WanVAEWrapper(vw.synth_vae_state_dict(vw.WAN_VAE, seed=0), device=dev)
+    lat = torch.randn(1, frames, 16, 60, 104, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(dev)
+    ms = timeit(lambda: vae.decode_to_pixel(lat), iters)
+    fl = vw.vae_decode_flops(vw.WAN_VAE, 60, 104, frames)
+    nf = 1 + 4 * (frames - 1)
+    print(f"vae decode {frames} latent frames -> {nf} frames 480x832: {ms:8.1f} ms  {nf / ms * 1e3:7.1f} frames/s  "
+          f"{fl / ms / 1e9:7.1f} TFLOP/s ({fl / 1e12:.1f} TFLOP)", flush=True)
 
 
 if __name__ == "__main__":
