@@ -17,7 +17,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   launch / its average launch duration, measured here with events on the launch
                   stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
   cpu_baseline -- the CPU oracle (oracle/wan_oracle.py, bf16 mode = the reference's CPU path)
-                  timed on this host's cores on a bounded sample (N = 1 only).
+                  timed on this host's cores on a bounded sample (N = 1 only);
+  vae_decode   -- SURVEY 8f-1, reported beside the metric (whose timed region is the DiT rollout,
+                  SURVEY 8d): the Wan VAE decode of one clip's latents to 81 frames of 480x832 pixels,
+                  and the literal rate of rollout + decode with the pixels left in HBM.
 """
 import argparse
 import json
@@ -172,6 +175,7 @@ def main():
     ap.add_argument("--model", default="Wan2.1-T2V-1.3B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
     ap.add_argument("--profile", action="store_true", help="print the pipeline's per-chunk event timing")
     ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
     a = ap.parse_args()
@@ -267,8 +271,43 @@ def main():
         att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs)
         out["roofline"] = att
         out["gemm"] = gemm
+    if rank == 0 and not a.no_vae:
+        # VAE decode: decode alone, then rollout + decode through the same pool
+        log("vae decode leg")
+        from self_forcing_amd import vae_weights as vw
+        vsd = vw.synth_vae_state_dict(vw.WAN_VAE, seed=0)
+        for pipe in pool.pipes:
+            pipe.vae = sfa.WanVAEWrapper(vsd, device=dev)
+        vae0 = pool.pipes[0].vae
+        vae0.decode_to_pixel(lat)                                    # allocates state + scratch
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        for _ in range(2):
+            pix = vae0.decode_to_pixel(lat)
+        torch.cuda.synchronize()
+        vae_s = (time.perf_counter() - tv) / 2
+        assert torch.isfinite(pix).all() and pix.shape[1] == decoded
+        vfl = vw.vae_decode_flops(vw.WAN_VAE, LAT_H, LAT_W, a.frames)
+
+        def literal_step(pipe, i):
+            noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
+            return pipe.inference(noise, [prompts[i]], return_latents=False)[0, -1, :, :2, :2].clone()
+
+        pool.run_each(lambda pipe: literal_step(pipe, 0))
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        pool.run(list(range(a.warmup, total)), literal_step)
+        torch.cuda.synchronize()
+        lit_s = time.perf_counter() - tl
+        out["vae_decode"] = {"ms_per_clip": 1e3 * vae_s, "frames_per_s": decoded / vae_s, "tflops": vfl / vae_s / 1e12,
+                             "algorithmic_tflop_per_clip": vfl / 1e12, "pixels": f"{decoded}x3x{8 * LAT_H}x{8 * LAT_W} float32",
+                             "rollout_plus_decode_frames_per_s": a.steps * decoded / lit_s,
+                             "note": "Wan2.1 VAE decoder shape, random-init weights; not part of `value`, whose timed "
+                                     "region is the DiT rollout (SURVEY 8d); the second rate is rollout + decode "
+                                     "through the same streams, pixels left in HBM"}
     if rank == 0 and not a.no_roofline:
         # streaming boundary: chunk-at-a-time generation on one stream, wall time per chunk
+        # (with the real VAE when the leg above installed it: the chunk's pixels are decoded before the yield)
         log("streaming leg")
         pipe0 = pool.pipes[0]
         noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
@@ -283,7 +322,8 @@ def main():
         out["streaming"] = {"first_chunk_ms": 1e3 * ts[0], "chunk_ms": [round(1e3 * t, 1) for t in ts],
                             "decoded_frames_per_chunk": 4 * nfpb, "steady_fps": 4 * nfpb * len(steady) / sum(steady),
                             "worst_chunk_fps": 4 * nfpb / max(steady), "realtime_playback_fps": 16,
-                            "note": "one rollout alone on the GPU; chunk k can be decoded/sent while k+1 is generated"}
+                            "pixels_decoded": not a.no_vae,
+                            "note": "one rollout alone on the GPU, each chunk denoised then decoded to pixels before it is yielded"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(shape, sd, 1, nfpb, len(step_list), a.frames)
     if dist is not None:

@@ -9,9 +9,12 @@ does not accept).
 Keeps the reference's semantics: OmegaConf-style merge of a default config under the run config,
 `DistributedSampler(shuffle=False, drop_last=True)` prompt sharding (rank r takes r, r+W, ...),
 seed = `--seed + rank`, noise `[num_samples, num_output_frames, 16, 60, 104]` bf16 drawn per prompt,
-one barrier after set-up.  What it writes are LATENTS (`<idx>-<sample>.pt`): the VAE and the umT5
-encoder are outside this path, so embeddings are synthetic unless `--prompt_embeds` (a .pt dict
-prompt -> [L, 4096] tensor) is given.
+one barrier after set-up.  It writes LATENTS (`<idx>-<sample>.pt`) and, when a VAE is given
+(`--vae_path Wan2.1_VAE.pth`, loaded with weights_only=True, or `--vae_random_init_seed N`), the decoded
+video as a uint8 tensor [T, H, W, 3] (`<idx>-<sample>.video.pt`: what the reference hands to
+`write_video`, inference.py:186-196; there is no video encoder in this image).  The umT5 encoder is
+outside this path, so embeddings are synthetic unless `--prompt_embeds` (a .pt dict prompt -> [L, 4096]
+tensor) is given.
 """
 import argparse
 import os
@@ -58,6 +61,8 @@ def main():
     ap.add_argument("--num_samples", type=int, default=1)
     ap.add_argument("--latent_height", type=int, default=60)
     ap.add_argument("--latent_width", type=int, default=104)
+    ap.add_argument("--vae_path", default=None, help="Wan2.1_VAE.pth: decode the latents to pixels")
+    ap.add_argument("--vae_random_init_seed", type=int, default=None, help="seeded random VAE decoder weights instead")
     a = ap.parse_args()
 
     dist = None
@@ -93,7 +98,13 @@ def main():
         enc = TableTextEncoder(torch.load(a.prompt_embeds, map_location="cpu", weights_only=True), shape.text_len, shape.text_dim, device)
     else:
         enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=device)
-    pipe = sfa.CausalInferencePipeline(cfg, device, generator=gen, text_encoder=enc, vae=sfa.IdentityVAE())
+    vae = sfa.IdentityVAE()
+    if a.vae_path:
+        vae = sfa.WanVAEWrapper(torch.load(a.vae_path, map_location="cpu", weights_only=True), device=device)
+    elif a.vae_random_init_seed is not None:
+        vae = sfa.WanVAEWrapper(sfa.synth_vae_state_dict(sfa.WAN_VAE, seed=a.vae_random_init_seed), device=device)
+    decode = not isinstance(vae, sfa.IdentityVAE)
+    pipe = sfa.CausalInferencePipeline(cfg, device, generator=gen, text_encoder=enc, vae=vae)
 
     if rank == 0:
         os.makedirs(a.output_folder, exist_ok=True)
@@ -103,11 +114,13 @@ def main():
     for idx in shard_indices(len(prompts), rank, world):
         noise = torch.randn([a.num_samples, a.num_output_frames, 16, a.latent_height, a.latent_width], device=device,
                             dtype=torch.bfloat16)
-        _, latents = pipe.inference(noise=noise, text_prompts=[prompts[idx]] * a.num_samples, return_latents=True)
+        video, latents = pipe.inference(noise=noise, text_prompts=[prompts[idx]] * a.num_samples, return_latents=True)
         for s in range(a.num_samples):
             torch.save(latents[s].cpu(), os.path.join(a.output_folder, f"{idx}-{s}.pt"))
+            if decode:   # [T, 3, H, W] in [0, 1] -> [T, H, W, 3] uint8 (inference.py:186-187)
+                torch.save((255.0 * video[s].permute(0, 2, 3, 1)).to(torch.uint8).cpu(), os.path.join(a.output_folder, f"{idx}-{s}.video.pt"))
         if rank == 0:
-            print(f"[generate] prompt {idx}: latents {tuple(latents.shape)}", flush=True)
+            print(f"[generate] prompt {idx}: latents {tuple(latents.shape)}" + (f", video {tuple(video.shape)}" if decode else ""), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

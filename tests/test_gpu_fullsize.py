@@ -116,11 +116,13 @@ def test_generate_cli_reduced(tmp_path):
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "generate.py"), "--config_path", str(cfg), "--data_path", str(prompts),
            "--output_folder", str(out), "--random_init_seed", "0", "--num_output_frames", "2", "--latent_height", "8",
-           "--latent_width", "12", "--seed", "5"]
+           "--latent_width", "12", "--seed", "5", "--vae_random_init_seed", "0"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     a, b = torch.load(out / "0-0.pt"), torch.load(out / "1-0.pt")
     assert a.shape == (2, 16, 8, 12) and torch.isfinite(a.float()).all() and not torch.equal(a, b)
+    vid = torch.load(out / "0-0.video.pt")     # decoded by the (random-init, full-width) VAE: [T, H, W, 3] uint8
+    assert vid.shape == (5, 64, 96, 3) and vid.dtype == torch.uint8 and vid.float().std() > 1
     # same seed, same prompt, in process -> same latents
     torch.manual_seed(5)
     gen = sfa.WanDiffusionWrapper(model_name="reduced", timestep_shift=5.0, is_causal=True, random_init_seed=0, device=DEV)

@@ -325,3 +325,48 @@ def test_pipeline_calls_foreign_generator_like_the_reference():
     assert pipe.denoising_step_list.dtype == torch.long          # un-warped list stays integer
     pipe.inference(torch.randn(1, 2, 16, 8, 12), ["p"])
     assert gen.calls == [0, 0, 0, 24, 24, 24]
+
+
+# ------------------------------------------------------------------------------------------ VAE host logic
+def test_vae_repack_conv_matches_convolution_definition():
+    """`repack_conv` lays weights out as [Cout][tap*Cin_pad + ci] with tap = (dt*kh + dh)*kw + dw: an explicit
+    gather-and-matmul with that layout must reproduce F.conv3d."""
+    import torch.nn.functional as F
+    from self_forcing_amd.vae import repack_conv
+    g = torch.Generator().manual_seed(0)
+    cin, cout, T, H, W = 5, 4, 2, 3, 4
+    x = torch.randn(cin, T + 2, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g)
+    rp = repack_conv(w)
+    assert rp.shape == (cout, 27 * 32 + 32) and rp.shape[1] % 64 == 0         # Cin 5 -> 32, K 864 -> 896
+    xp = F.pad(x, (1, 1, 1, 1, 0, 0))
+    cols = torch.zeros(T, H, W, rp.shape[1])
+    for dt in range(3):
+        for dh in range(3):
+            for dw in range(3):
+                tap = (dt * 3 + dh) * 3 + dw
+                cols[..., tap * 32:tap * 32 + cin] = xp[:, dt:dt + T, dh:dh + H, dw:dw + W].permute(1, 2, 3, 0)
+    ref = F.conv3d(xp[None], w)[0].permute(1, 2, 3, 0)
+    assert torch.allclose(cols @ rp.t(), ref, atol=1e-4)
+    # Conv2d weights are treated as kt = 1
+    assert repack_conv(torch.randn(8, 64, 3, 3)).shape == (8, 9 * 64)
+
+
+def test_vae_decode_flops_and_frame_counts():
+    from self_forcing_amd import vae_weights as vw
+    one = vw.vae_decode_flops(vw.WAN_VAE, 60, 104, 1)
+    two = vw.vae_decode_flops(vw.WAN_VAE, 60, 104, 2)
+    assert 13.0e12 < two - one < 14.0e12          # ~13.6 TFLOP per steady latent frame at 832x480
+    assert one < (two - one) / 3                  # the first latent frame yields 1 pixel frame, not 4
+    assert vw.WAN_VAE.temporal_factor == 4 and vw.WAN_VAE.spatial_factor == 8
+    mid, ups = vw.decoder_layout(vw.WAN_VAE)
+    assert [u.mode for u in ups if isinstance(u, vw.ResampleSpec)] == ["upsample3d", "upsample3d", "upsample2d"]
+    assert len([u for u in ups if isinstance(u, vw.ResBlockSpec)]) == 12
+
+
+def test_vae_wrapper_has_no_cpu_fallback():
+    from self_forcing_amd import vae_weights as vw
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises((RuntimeError, AssertionError)):
+        sfa.WanVAEWrapper(vw.synth_vae_state_dict(vw.VAE_REDUCED, seed=0), device="cuda:0", shape=vw.VAE_REDUCED)
