@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
+#include "attention_r64_asm.inc"
 
 namespace {
 
@@ -636,6 +637,90 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
 
 
 
+// ------------------------------------------------------------------------------------------
+// 64 query rows per wave, one wave per SIMD, hand-scheduled: the C++ below only computes the per-lane
+// addresses (same layouts and formulas as the kernels above) and hands them to the generated assembly
+// body through LDS; tools/gen_attention_r64.py documents the register map and the pipeline.
+constexpr int QT64 = 256;                      // 4 waves x 64 rows
+constexpr int ATT64_LDS = 5 * TILE_B;          // K ring of 3 + V ring of 2 = 80 KiB
+
+__global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int bh = wg / p.q_tiles, qt = wg - bh * p.q_tiles;
+  const int b = bh / p.H, head = bh - b * p.H;
+  const bf16_t* qbase = p.q + (long)b * p.q_bstride + head * HD;
+  const bf16_t* kbase = p.k + (long)b * p.kv_bstride + head * HD;
+  const bf16_t* vbase = p.v + (long)b * p.kv_bstride + head * HD;
+  bf16_t* obase = p.o + (long)b * p.o_bstride + head * HD;
+
+  const int r32 = lane & 31, hh = lane >> 5;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  unsigned prm[SF_R64_N_PARAM];
+  {
+    const int x = hh ^ (((r32 & 3) << 2) | ((r32 >> 2) & 3));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) prm[s] = lds_base + 256 * r32 + 16 * ((2 * s) ^ x);
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int tq = i16 >> 2, tp = i16 & 3;
+    const int y = 2 * (g16 & 1) + (tp >> 1);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      prm[8 + db] = lds_base + 256 * (4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ hh)) + 8 * (tp & 1);
+      prm[12 + db] = lds_base + 256 * (8 + 4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ (hh + 2))) + 8 * (tp & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // this wave's LDS-DMA pieces 4 wave + i: 4 rows x 256 B each, swizzle on the source
+      const int row = (wave * 4 + i) * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      prm[16 + i] = (unsigned)(((long)row * p.kv_stride + chunk * 8) * 2);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qrow = qt * QT64 + wave * 64 + qb * 32 + r32;
+      const unsigned long long qa = (unsigned long long)(qbase + (long)min(qrow, p.Lq - 1) * p.q_stride + 8 * hh);
+      const unsigned long long oa = (unsigned long long)(obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 4 * hh);
+      prm[20 + 2 * qb] = (unsigned)qa; prm[21 + 2 * qb] = (unsigned)(qa >> 32);
+      prm[24 + 2 * qb] = (unsigned)oa; prm[25 + 2 * qb] = (unsigned)(oa >> 32);
+      prm[29 + qb] = qrow < p.Lq ? 1u : 0u;
+    }
+    prm[28] = 4 * hh;
+  }
+  unsigned* pl = reinterpret_cast<unsigned*>(smem);
+#pragma unroll
+  for (int j = 0; j < SF_R64_N_PARAM; ++j) pl[j * 256 + tid] = prm[j];
+
+  const unsigned kv_bytes = (unsigned)(((long)(p.Lk - 1) * p.kv_stride + HD) * 2);
+  auto make_srd = [&](const bf16_t* base) {
+    const unsigned long long a64 = (unsigned long long)base;
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((unsigned)a64);
+    d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a64 >> 32) & 0xFFFFu);
+    d[2] = __builtin_amdgcn_readfirstlane(kv_bytes);
+    d[3] = 0x00020000u;
+    return d;
+  };
+  const u32x4 k_srd = make_srd(kbase), v_srd = make_srd(vbase);
+  const unsigned tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)((long)KT * p.kv_stride * 2));
+  const int ntiles = __builtin_amdgcn_readfirstlane((p.Lk + KT - 1) / KT);
+  const int lk = __builtin_amdgcn_readfirstlane(p.Lk);
+  const unsigned cbits = __builtin_amdgcn_readfirstlane(__float_as_uint(p.scale_log2));
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 4096u);
+  const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_base);
+  const unsigned tid4 = lds_base + 4u * (unsigned)tid;
+  asm volatile(SF_R64_ASM_BODY
+               :
+               : "s"(k_srd), "s"(v_srd), "s"(tile_bytes), "s"(ntiles), "s"(lk), "s"(cbits), "s"(lds_wave), "v"(tid4), "s"(lds_b)
+               : SF_R64_CLOBBERS);
+}
+
+
 }  // namespace
 
 extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
@@ -657,6 +742,18 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
   // 256-row / 8-wave structure when it fills most of the chip's 256 CUs in whole rounds, else
   // 128-row / 4-wave workgroups (two per CU)
+  if (getenv("SF_ATTN_R64")) {   // A/B switch while the hand-scheduled kernel is being brought up
+    p.q_tiles = (Lq + QT64 - 1) / QT64;
+    const long nwg64 = (long)p.q_tiles * H * B;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);
+      attr = true;
+    }
+    hipLaunchKernelGGL(attention_r64_kernel, dim3((unsigned)nwg64), dim3(256), ATT64_LDS, (hipStream_t)stream, p);
+    SF_HIP_LAUNCH_CHECK("sf_attention");
+    return 0;
+  }
   const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
   if ((nwg8 >= 192 && !getenv("SF_ATTN_W4")) || getenv("SF_ATTN_W8")) {   // env switches: A/B timing and tests only
     p.q_tiles = (Lq + QT8 - 1) / QT8;

@@ -1,0 +1,446 @@
+#!/usr/bin/env python
+"""Generator of the hand-scheduled 64-query-rows-per-wave attention kernel body for gfx950.
+
+Writes self-forcing_amd/csrc/attention_r64_asm.inc: ONE inline-asm string, the whole kernel after the
+C++ prologue of attention_r64.hip (which computes the per-lane addresses with the same formulas as the
+other attention kernels and hands them over through LDS).  Run it again after editing; the .inc is
+committed so that the build needs no Python.
+
+Why assembly: with 64 query rows per wave every K / V^T fragment read from LDS feeds TWO MFMAs
+(19 instead of 34 LDS bytes per kflop -- the measured limiter of the 32-row kernels), but the wave then
+needs all 512 registers (O^T in AGPRs, one wave per SIMD), and softmax VALU, LDS reads and MFMAs have to
+be interleaved by hand inside the single instruction stream; hipcc's allocator/scheduler does not
+produce that.
+
+Per wave: 64 queries = two 32-query blocks A, B (MFMA 32x32x16 column blocks).  Keys in tiles of 64 =
+two 32-key units.  Registers:
+  AGPR  a[0:127]   O^T accumulators  O[qb][db]   (qb 0..1, db 0..3: 32 head dims each)
+        a[128:191] Q^T fragments     Q[qb][s]    (s 0..7: 16 head dims each)
+  VGPR  S0, S1     S^T accumulators of the unit being produced / consumed (2 x 32)
+        P0, P1     bf16 P^T fragments (2 x 16)
+        KF, VF     K and V^T fragment slots (8 x 4 each)
+Pipeline per tile t (units u0 = 2t, u1 = 2t+1), one s_barrier per tile, K ring of 3 slots, V ring of 2:
+  0  wait own LDS-DMA, barrier (K(t+1), V(t) landed); request K(t+2), V(t+1)
+  A  QK(u1) -> S1      ||  softmax(u0): S0 -> P0   ||  read V^T fragments of u0
+  B  PV(u0)            ||  read K fragments of unit 0 of tile t+1
+  C  QK(2t+2) -> S0    ||  softmax(u1): S1 -> P1   ||  read V^T fragments of u1
+  D  PV(u1)            ||  read K fragments of unit 1 of tile t+1
+The last tile runs the masked softmax (keys >= Lk -> -1e30) and drops the QK / K reads of tile t+1.
+"""
+import os
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "self-forcing_amd", "csrc",
+                   "attention_r64_asm.inc")
+
+# ---- inline-asm operands (inputs only)
+K_SRD, V_SRD, TILE_BYTES, NTILES, LK, CSCALE, LDS_WAVE, TID4, LDS_BASE = "%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8"
+
+# ---- register map
+KADDR = [1 + i for i in range(8)]
+VLO = [9 + i for i in range(4)]
+VHI = [13 + i for i in range(4)]
+DMAOFF = [17 + i for i in range(4)]
+QP = [22, 24]
+OP = [26, 28]
+HH4, VALID = 30, [31, 32]
+KCUR = [33 + i for i in range(8)]
+VCURLO = [41 + i for i in range(4)]
+VCURHI = [45 + i for i in range(4)]
+S = [64, 96]          # S[buf] + qb*16
+P = [128, 144]        # P[buf] + qb*8 + ks*4
+KF, VF = 160, 192
+TMP = 224
+MX = [240, 241]
+MRUN = [242, 243]
+L2 = [244, 246]
+MC = [248, 250]
+ALPHA = 252
+NEG = 254
+SCR = 255
+A_O = lambda qb, db: (qb * 4 + db) * 16          # noqa: E731
+A_Q = lambda qb, s: 128 + (qb * 8 + s) * 4       # noqa: E731
+N_PARAM = 31
+
+ST, NTM1, KS_CUR, KS_NEXT, KS_DMA, VS_CUR, VS_DMA, STMP = 60, 61, 62, 63, 64, 65, 66, 67
+C2, NEGC, SVCC, SEXEC, SOFFK, SOFFV, SLIM, STMP2 = 68, 70, 72, 74, 76, 77, 78, 79
+K_RING, V_BASE = 3 * 16384, 3 * 16384
+
+out = []
+
+
+def e(s):
+    out.append(s)
+
+
+def vr(base, n=1):
+    return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
+
+
+def ar(base, n=1):
+    return f"a{base}" if n == 1 else f"a[{base}:{base + n - 1}]"
+
+
+class Lds:
+    """in-order LDS read tracker -> exact s_waitcnt lgkmcnt before each consumer"""
+
+    def __init__(self):
+        self.issued = 0
+        self.done = 0      # reads with index < done are known complete
+
+    def read(self, text):
+        e(text)
+        self.issued += 1
+        return self.issued - 1
+
+    def need(self, idx):
+        if idx < self.done:
+            return
+        after = self.issued - 1 - idx
+        e(f"s_waitcnt lgkmcnt({min(after, 15)})")
+        self.done = max(self.done, idx + 1) if after <= 15 else self.done
+
+    def reset(self, in_flight):
+        self.issued, self.done = in_flight, 0
+
+
+lds = Lds()
+
+
+def k_reads(kb):
+    """the 8 K fragments (one per 16-wide head-dim step) of a 32-key unit -> KF slots"""
+    return [("lds", f"ds_read_b128 {vr(KF + 4 * s, 4)}, {vr(KCUR[s])} offset:{kb * 8192}", ("k", s)) for s in range(8)]
+
+
+def v_reads(kb):
+    """the 8 V^T fragments (2 key steps x 4 head-dim blocks) of a 32-key unit -> VF slots (lo, hi halves)"""
+    r = []
+    for ks in range(2):
+        for db in range(4):
+            f = ks * 4 + db
+            off = (2 * kb + ks) * 4096
+            r.append(("lds", f"ds_read_b64_tr_b16 {vr(VF + 4 * f, 2)}, {vr(VCURLO[db])} offset:{off}", ("vlo", f)))
+            r.append(("lds", f"ds_read_b64_tr_b16 {vr(VF + 4 * f + 2, 2)}, {vr(VCURHI[db])} offset:{off}", ("vhi", f)))
+    return r
+
+
+def qk_mfmas(sbuf):
+    m = []
+    for s in range(8):
+        for qb in range(2):
+            acc = vr(S[sbuf] + 16 * qb, 16)
+            m.append((f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(KF + 4 * s, 4)}, {ar(A_Q(qb, s), 4)}, {'0' if s == 0 else acc}", [("k", s)]))
+    return m
+
+
+def pv_mfmas(pbuf):
+    m = []
+    for ks in range(2):
+        for db in range(4):
+            f = ks * 4 + db
+            for qb in range(2):
+                acc = ar(A_O(qb, db), 16)
+                m.append((f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(VF + 4 * f, 4)}, {vr(P[pbuf] + 8 * qb + 4 * ks, 4)}, {acc}", [("vlo", f), ("vhi", f)]))
+    return m
+
+
+label_n = [0]
+
+
+def new_label(stem):
+    label_n[0] += 1
+    return f".Lr64_{stem}_{label_n[0]}%="
+
+
+def softmax_items(sbuf, pbuf, masked, kb):
+    """VALU stream of one unit's online softmax for both query blocks; ("raw", text) items may be
+    control flow (the rare O rescale), everything else is one instruction per item."""
+    it = []
+    sreg = lambda qb, r: S[sbuf] + 16 * qb + r   # noqa: E731
+    if masked:
+        # keys of this unit at or past Lk: key = 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 hh ; SLIM = Lk - 64 t
+        for r in range(16):
+            it.append(("valu", f"s_sub_i32 s{STMP}, s{SLIM}, {32 * kb + (r & 3) + 8 * (r >> 2)}"))
+            it.append(("valu", f"v_cmp_le_i32 vcc, s{STMP}, {vr(HH4)}"))
+            for qb in range(2):
+                it.append(("valu", f"v_cndmask_b32 {vr(sreg(qb, r))}, {vr(sreg(qb, r))}, {vr(NEG)}, vcc"))
+    for qb in range(2):
+        it.append(("valu", f"v_max3_f32 {vr(MX[qb])}, {vr(sreg(qb, 0))}, {vr(sreg(qb, 1))}, {vr(sreg(qb, 2))}"))
+    for j in range(6):
+        for qb in range(2):
+            it.append(("valu", f"v_max3_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(sreg(qb, 3 + 2 * j))}, {vr(sreg(qb, 4 + 2 * j))}"))
+    for qb in range(2):
+        it.append(("valu", f"v_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(sreg(qb, 15))}"))
+    for qb in range(2):   # across the lane pair (l, l+32) that shares a query column
+        it.append(("valu", f"v_mov_b32 {vr(TMP + qb)}, {vr(MX[qb])}"))
+    for qb in range(2):
+        it.append(("valu", f"s_nop 0\n\tv_permlane32_swap_b32 {vr(MX[qb])}, {vr(TMP + qb)}"))
+    for qb in range(2):
+        it.append(("valu", f"s_nop 0\n\tv_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(TMP + qb)}"))
+    # any row whose maximum grew?  (wave-uniform branch; the rescale is rare after the first tiles)
+    skip = new_label("norescale")
+    txt = [f"v_cmp_gt_f32 vcc, {vr(MX[0])}, {vr(MRUN[0])}", f"s_mov_b64 s[{SVCC}:{SVCC + 1}], vcc",
+           f"v_cmp_gt_f32 vcc, {vr(MX[1])}, {vr(MRUN[1])}", f"s_or_b64 vcc, vcc, s[{SVCC}:{SVCC + 1}]", "s_nop 1",
+           f"s_cbranch_vccz {skip}"]
+    for qb in range(2):
+        txt += [f"v_max_f32 {vr(TMP + 2)}, {vr(MRUN[qb])}, {vr(MX[qb])}",
+                f"v_sub_f32 {vr(TMP + 3)}, {vr(MRUN[qb])}, {vr(TMP + 2)}",
+                f"v_mov_b32 {vr(MRUN[qb])}, {vr(TMP + 2)}",
+                f"v_mul_f32 {vr(TMP + 3)}, s{C2}, {vr(TMP + 3)}",
+                f"v_exp_f32 {vr(ALPHA)}, {vr(TMP + 3)}", "s_nop 1",
+                f"v_pk_mul_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(ALPHA, 2)} op_sel_hi:[1,0]"]
+        for db in range(4):
+            base = A_O(qb, db)
+            for i in range(16):
+                txt.append(f"v_accvgpr_read_b32 {vr(SCR)}, {ar(base + i)}")
+                txt.append("s_nop 0")
+                txt.append(f"v_mul_f32 {vr(SCR)}, {vr(SCR)}, {vr(ALPHA)}")
+                txt.append("s_nop 0")
+                txt.append(f"v_accvgpr_write_b32 {ar(base + i)}, {vr(SCR)}")
+    txt += ["s_nop 4", f"{skip}:"]
+    it.append(("raw", "\n\t".join(txt)))
+    for qb in range(2):
+        it.append(("valu", f"v_mul_f32 {vr(MC[qb])}, s{NEGC}, {vr(MRUN[qb])}"))
+    for r in range(0, 16, 2):
+        for qb in range(2):
+            x = vr(sreg(qb, r), 2)
+            it.append(("valu", f"v_pk_fma_f32 {x}, {x}, s[{C2}:{C2 + 1}], {vr(MC[qb], 2)} op_sel_hi:[1,1,0]"))
+    for r in range(16):
+        for qb in range(2):
+            it.append(("valu", f"v_exp_f32 {vr(sreg(qb, r))}, {vr(sreg(qb, r))}"))
+    for r in range(0, 16, 2):
+        for qb in range(2):
+            it.append(("valu", f"v_pk_add_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(sreg(qb, r), 2)}"))
+    for r in range(0, 16, 2):   # P^T fragment of key step ks = r >> 3, element pair (r & 7) >> 1
+        for qb in range(2):
+            dst = P[pbuf] + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1)
+            it.append(("valu", f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(sreg(qb, r))}, {vr(sreg(qb, r + 1))}"))
+    it.append(("valu", "s_nop 1"))
+    return it
+
+
+def mix(a, b):
+    """b spread evenly through a (order within each list kept)"""
+    if not a:
+        return list(b)
+    res, bi = [], 0
+    for i, x in enumerate(a):
+        res.append(x)
+        want = len(b) * (i + 1) // len(a)
+        while bi < want:
+            res.append(b[bi])
+            bi += 1
+    return res + list(b[bi:])
+
+
+def phase(mfmas, others):
+    """emit `mfmas` with `others` spread evenly behind them; LDS waits are derived from the tracker"""
+    tags = phase.tags
+    n = max(1, len(mfmas))
+    per = [len(others) * (i + 1) // n - len(others) * i // n for i in range(n)] if mfmas else []
+    oi = 0
+
+    def emit_other(item):
+        kind = item[0]
+        if kind == "lds":
+            tags[item[2]] = lds.read(item[1])
+        else:
+            e(item[1])
+
+    if not mfmas:
+        for item in others:
+            emit_other(item)
+        return
+    for i, (text, needs) in enumerate(mfmas):
+        for tg in needs:
+            lds.need(tags[tg])
+        e(text)
+        for _ in range(per[i]):
+            emit_other(others[oi])
+            oi += 1
+    while oi < len(others):
+        emit_other(others[oi])
+        oi += 1
+
+
+phase.tags = {}
+
+
+def dma(srd, soff_sreg, slot_sreg):
+    """this wave's four 1 KiB pieces of a K or V tile: global -> LDS, range-checked, swizzle on the source"""
+    for i in range(4):
+        e(f"s_add_u32 s{STMP2}, s{slot_sreg}, {LDS_WAVE}")
+        if i:
+            e(f"s_add_u32 s{STMP2}, s{STMP2}, {i * 1024}")
+        e(f"s_mov_b32 m0, s{STMP2}")
+        e("s_nop 2")
+        e(f"buffer_load_dwordx4 {vr(DMAOFF[i])}, {srd}, s{soff_sreg} offen lds")
+
+
+def set_kcur(slot_sreg):
+    return [("valu", f"v_add_u32 {vr(KCUR[s])}, s{slot_sreg}, {vr(KADDR[s])}") for s in range(8)]
+
+
+def set_vcur(slot_sreg):
+    return ([("valu", f"v_add_u32 {vr(VCURLO[d])}, s{slot_sreg}, {vr(VLO[d])}") for d in range(4)]
+            + [("valu", f"v_add_u32 {vr(VCURHI[d])}, s{slot_sreg}, {vr(VHI[d])}") for d in range(4)])
+
+
+def body(last):
+    # in flight at entry: the 8 K fragment reads of unit 1 of tile t (issued by the previous phase D / prologue)
+    lds.reset(8)
+    phase.tags = {("k", s): s for s in range(8)}
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    if not last:
+        # request K(min(t+2, nt-1)) and V(min(t+1, nt-1))
+        e(f"s_add_u32 s{STMP}, s{ST}, 2")
+        e(f"s_min_u32 s{STMP}, s{STMP}, s{NTM1}")
+        e(f"s_mul_i32 s{SOFFK}, s{STMP}, {TILE_BYTES}")
+        e(f"s_add_u32 s{STMP}, s{ST}, 1")
+        e(f"s_min_u32 s{STMP}, s{STMP}, s{NTM1}")
+        e(f"s_mul_i32 s{SOFFV}, s{STMP}, {TILE_BYTES}")
+        dma(K_SRD, SOFFK, KS_DMA)
+        dma(V_SRD, SOFFV, VS_DMA)
+    else:
+        e(f"s_lshl_b32 s{STMP}, s{ST}, 6")
+        e(f"s_sub_i32 s{SLIM}, {LK}, s{STMP}")
+    # A
+    phase(qk_mfmas(1), mix(softmax_items(0, 0, last, 0), v_reads(0)))
+    # B
+    phase(pv_mfmas(0), [] if last else set_kcur(KS_NEXT) + k_reads(0))
+    # C
+    phase([] if last else qk_mfmas(0), v_reads(1) + softmax_items(1, 1, last, 1) if last else mix(softmax_items(1, 1, last, 1), v_reads(1)))
+    # D
+    phase(pv_mfmas(1), [] if last else k_reads(1))
+    if not last:
+        # rotate the rings: K (cur, next, dma) <- (next, dma, cur); V (cur, dma) swap
+        e(f"s_mov_b32 s{STMP}, s{KS_CUR}")
+        e(f"s_mov_b32 s{KS_CUR}, s{KS_NEXT}")
+        e(f"s_mov_b32 s{KS_NEXT}, s{KS_DMA}")
+        e(f"s_mov_b32 s{KS_DMA}, s{STMP}")
+        e(f"s_mov_b32 s{STMP}, s{VS_CUR}")
+        e(f"s_mov_b32 s{VS_CUR}, s{VS_DMA}")
+        e(f"s_mov_b32 s{VS_DMA}, s{STMP}")
+        for _, t in set_vcur(VS_CUR):
+            e(t)
+        e(f"s_add_u32 s{ST}, s{ST}, 1")
+
+
+def main():
+    e("; ---- parameters handed over through LDS: dword j of lane tid at byte j*1024 + tid*4")
+    dst = KADDR + VLO + VHI + DMAOFF + [QP[0], QP[0] + 1, QP[1], QP[1] + 1, OP[0], OP[0] + 1, OP[1], OP[1] + 1, HH4] + VALID
+    assert len(dst) == N_PARAM
+    for j, d in enumerate(dst):
+        e(f"ds_read_b32 {vr(d)}, {TID4} offset:{j * 1024}")
+        if j % 8 == 7:
+            e("s_waitcnt lgkmcnt(0)")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")
+    e("; ---- constants and state")
+    e(f"s_mov_b32 s{C2}, {CSCALE}")
+    e(f"s_mov_b32 s{C2 + 1}, {CSCALE}")
+    e(f"s_xor_b32 s{NEGC}, {CSCALE}, 0x80000000")
+    e(f"v_mov_b32 {vr(NEG)}, 0xf149f2ca")          # -1e30
+    for qb in range(2):
+        e(f"v_mov_b32 {vr(MRUN[qb])}, {vr(NEG)}")
+        e(f"v_mov_b32 {vr(L2[qb])}, 0")
+        e(f"v_mov_b32 {vr(L2[qb] + 1)}, 0")
+        e(f"v_mov_b32 {vr(MC[qb] + 1)}, 0")
+    e(f"v_mov_b32 {vr(ALPHA + 1)}, 0")
+    e(f"s_sub_u32 s{NTM1}, {NTILES}, 1")
+    e(f"s_mov_b32 s{ST}, 0")
+    e(f"s_mov_b32 s{KS_CUR}, 0")
+    e(f"s_mov_b32 s{KS_NEXT}, 16384")
+    e(f"s_mov_b32 s{KS_DMA}, 32768")
+    e(f"s_mov_b32 s{VS_CUR}, {V_BASE}")
+    e(f"s_mov_b32 s{VS_DMA}, {V_BASE + 16384}")
+    e("; ---- zero the five LDS slots (rows past Lk are never fetched; 0 * stale NaN would poison P.V)")
+    e(f"v_mov_b32 {vr(TMP)}, 0")
+    e(f"v_mov_b32 {vr(TMP + 1)}, 0")
+    e(f"v_mov_b32 {vr(TMP + 2)}, 0")
+    e(f"v_mov_b32 {vr(TMP + 3)}, 0")
+    e(f"v_subrev_u32 {vr(TMP + 4)}, {LDS_BASE}, {TID4}")    # TID4 = lds base + tid*4
+    e(f"v_lshlrev_b32 {vr(TMP + 4)}, 2, {vr(TMP + 4)}")
+    e(f"v_add_u32 {vr(TMP + 4)}, {LDS_BASE}, {vr(TMP + 4)}")   # lds base + tid*16
+    e(f"v_add_u32 {vr(TMP + 5)}, 40960, {vr(TMP + 4)}")
+    for i in range(20):
+        e(f"ds_write_b128 {vr(TMP + 4 + i // 10)}, {vr(TMP, 4)} offset:{(i % 10) * 4096}")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")
+    e("; ---- Q^T fragments -> AGPRs, O^T = 0")
+    for qb in range(2):
+        for s in range(8):
+            e(f"global_load_dwordx4 {vr(S[0] + (qb * 8 + s) * 4, 4)}, {vr(QP[qb], 2)}, off offset:{s * 32}")
+    for i in range(128):
+        e(f"v_accvgpr_write_b32 {ar(i)}, 0")
+    e("; ---- first tiles: K(0), K(1), V(0)")
+    e(f"s_mov_b32 s{SOFFK}, 0")
+    dma(K_SRD, SOFFK, KS_CUR)
+    dma(V_SRD, SOFFK, VS_CUR)
+    e(f"s_min_u32 s{STMP}, s{NTM1}, 1")
+    e(f"s_mul_i32 s{SOFFK}, s{STMP}, {TILE_BYTES}")
+    dma(K_SRD, SOFFK, KS_NEXT)
+    e("s_waitcnt vmcnt(0)")
+    for i in range(64):
+        e(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(S[0] + i)}")
+    e("s_nop 4")
+    e("s_barrier")
+    for _, t in set_kcur(KS_CUR):
+        e(t)
+    for _, t in set_vcur(VS_CUR):
+        e(t)
+    e("; ---- QK of unit 0, then the K fragments of unit 1 in flight for the loop")
+    lds.reset(0)
+    phase.tags = {}
+    phase([], k_reads(0))
+    phase(qk_mfmas(0), [])
+    phase([], k_reads(1))
+    loop, last_l = ".Lr64_loop%=", ".Lr64_last%="
+    e(f"{loop}:")
+    e(f"s_cmp_eq_u32 s{ST}, s{NTM1}")
+    e(f"s_cbranch_scc1 {last_l}")
+    body(False)
+    e(f"s_branch {loop}")
+    e(f"{last_l}:")
+    body(True)
+    e("; ---- epilogue: O / l -> bf16, rows past Lq masked off")
+    e("s_nop 7")
+    e("s_nop 7")
+    e("s_nop 7")
+    for qb in range(2):
+        e(f"v_add_f32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(L2[qb] + 1)}")
+        e(f"v_mov_b32 {vr(TMP)}, {vr(L2[qb])}")
+        e("s_nop 0")
+        e(f"v_permlane32_swap_b32 {vr(L2[qb])}, {vr(TMP)}")
+        e("s_nop 0")
+        e(f"v_add_f32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(TMP)}")
+        e(f"v_rcp_f32 {vr(ALPHA)}, {vr(L2[qb])}")
+        e("s_nop 1")
+        e(f"v_cmp_ne_u32 vcc, 0, {vr(VALID[qb])}")
+        e(f"s_and_saveexec_b64 s[{SEXEC}:{SEXEC + 1}], vcc")
+        for db in range(4):
+            for i in range(16):
+                e(f"v_accvgpr_read_b32 {vr(S[0] + i)}, {ar(A_O(qb, db) + i)}")
+            e("s_nop 1")
+            for i in range(16):
+                e(f"v_mul_f32 {vr(S[0] + i)}, {vr(S[0] + i)}, {vr(ALPHA)}")
+            for i in range(8):
+                e(f"v_cvt_pk_bf16_f32 {vr(S[1] + i)}, {vr(S[0] + 2 * i)}, {vr(S[0] + 2 * i + 1)}")
+            for rg in range(4):
+                e(f"global_store_dwordx2 {vr(OP[qb], 2)}, {vr(S[1] + 2 * rg, 2)}, off offset:{db * 64 + rg * 16}")
+            e("s_waitcnt vmcnt(0)")
+        e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
+    body_txt = "\n".join('    "' + ln.replace("\n\t", '\\n\\t') + '\\n"' for ln in out)
+    clob_v = ", ".join(f'"v{i}"' for i in range(1, 256))
+    clob_a = ", ".join(f'"a{i}"' for i in range(0, 192))
+    clob_s = ", ".join(f'"s{i}"' for i in range(60, 80))
+    with open(OUT, "w") as f:
+        f.write("// GENERATED by tools/gen_attention_r64.py -- do not edit; see that file for the design.\n")
+        f.write(f"#define SF_R64_N_PARAM {N_PARAM}\n")
+        f.write("#define SF_R64_ASM_BODY \\\n" + body_txt.replace("\n", " \\\n") + "\n")
+        f.write(f"#define SF_R64_CLOBBERS {clob_v}, {clob_a}, {clob_s}, \"vcc\", \"scc\", \"memory\"\n")
+    print(f"wrote {OUT}: {len(out)} asm lines")
+
+
+if __name__ == "__main__":
+    main()
