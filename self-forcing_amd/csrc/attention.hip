@@ -24,7 +24,10 @@
 #include <type_traits>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
-#include "attention_r64_asm.inc"
+#ifndef SF_R64_INC
+#define SF_R64_INC "attention_r64_asm.inc"   // timing-only ablation builds substitute their own (tools/gen_attention_r64.py --abl)
+#endif
+#include SF_R64_INC
 
 namespace {
 

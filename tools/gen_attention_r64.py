@@ -28,12 +28,18 @@ Pipeline per tile t (units u0 = 2t, u1 = 2t+1), one s_barrier per tile, K ring o
 The last tile runs the masked softmax (keys >= Lk -> -1e30) and drops the QK / K reads of tile t+1.
 """
 import os
+import sys
+
+ABL = set()          # timing-only ablations: nosoftmax, nolds, nomfma, nodma, nobarrier, norescale
+if "--abl" in sys.argv:
+    ABL = set(sys.argv[sys.argv.index("--abl") + 1].split(","))
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "self-forcing_amd", "csrc",
                    "attention_r64_asm.inc")
 
 # ---- inline-asm operands (inputs only)
 K_SRD, V_SRD, TILE_BYTES, NTILES, LK, CSCALE, LDS_WAVE, TID4, LDS_BASE = "%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8"
+THR = "v21"   # lazy-rescale threshold 8 / c, computed in the prologue
 
 # ---- register map
 KADDR = [1 + i for i in range(8)]
@@ -93,7 +99,7 @@ class Lds:
         return self.issued - 1
 
     def need(self, idx):
-        if idx < self.done:
+        if idx < self.done or idx < 0:
             return
         after = self.issued - 1 - idx
         e(f"s_waitcnt lgkmcnt({min(after, 15)})")
@@ -156,6 +162,13 @@ def softmax_items(sbuf, pbuf, masked, kb):
     control flow (the rare O rescale), everything else is one instruction per item."""
     it = []
     sreg = lambda qb, r: S[sbuf] + 16 * qb + r   # noqa: E731
+    if "nosoftmax" in ABL:
+        for r in range(0, 16, 2):
+            for qb in range(2):
+                dst = P[pbuf] + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1)
+                it.append(("valu", f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(sreg(qb, r))}, {vr(sreg(qb, r + 1))}"))
+        it.append(("valu", "s_nop 1"))
+        return it
     if masked:
         # keys of this unit at or past Lk: key = 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 hh ; SLIM = Lk - 64 t
         for r in range(16):
@@ -176,11 +189,15 @@ def softmax_items(sbuf, pbuf, masked, kb):
         it.append(("valu", f"s_nop 0\n\tv_permlane32_swap_b32 {vr(MX[qb])}, {vr(TMP + qb)}"))
     for qb in range(2):
         it.append(("valu", f"s_nop 0\n\tv_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(TMP + qb)}"))
-    # any row whose maximum grew?  (wave-uniform branch; the rescale is rare after the first tiles)
+    # Lazy rescale: the running maximum m is only a reference point -- exp2((s - m) c) stays exact for any
+    # m as long as it does not overflow -- so O and l are rescaled only when some row's maximum has grown
+    # by more than THR = 8 / c (P <= 2^8, harmless in bf16 / fp32).  With O in AGPRs a rescale costs
+    # ~330 instructions; the exact policy (rescale whenever any of the wave's 128 rows sees a new maximum)
+    # fired in most tiles and cost 40 % of the kernel.
     skip = new_label("norescale")
-    txt = [f"v_cmp_gt_f32 vcc, {vr(MX[0])}, {vr(MRUN[0])}", f"s_mov_b64 s[{SVCC}:{SVCC + 1}], vcc",
-           f"v_cmp_gt_f32 vcc, {vr(MX[1])}, {vr(MRUN[1])}", f"s_or_b64 vcc, vcc, s[{SVCC}:{SVCC + 1}]", "s_nop 1",
-           f"s_cbranch_vccz {skip}"]
+    txt = [f"v_sub_f32 {vr(TMP + 2)}, {vr(MX[0])}, {vr(MRUN[0])}", f"v_sub_f32 {vr(TMP + 3)}, {vr(MX[1])}, {vr(MRUN[1])}",
+           f"v_max_f32 {vr(TMP + 2)}, {vr(TMP + 2)}, {vr(TMP + 3)}",
+           f"v_cmp_lt_f32 vcc, {THR}, {vr(TMP + 2)}", "s_nop 1", f"s_cbranch_vccz {skip}"]
     for qb in range(2):
         txt += [f"v_max_f32 {vr(TMP + 2)}, {vr(MRUN[qb])}, {vr(MX[qb])}",
                 f"v_sub_f32 {vr(TMP + 3)}, {vr(MRUN[qb])}, {vr(TMP + 2)}",
@@ -188,14 +205,10 @@ def softmax_items(sbuf, pbuf, masked, kb):
                 f"v_mul_f32 {vr(TMP + 3)}, s{C2}, {vr(TMP + 3)}",
                 f"v_exp_f32 {vr(ALPHA)}, {vr(TMP + 3)}", "s_nop 1",
                 f"v_pk_mul_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(ALPHA, 2)} op_sel_hi:[1,0]"]
-        for db in range(4):
-            base = A_O(qb, db)
-            for i in range(16):
-                txt.append(f"v_accvgpr_read_b32 {vr(SCR)}, {ar(base + i)}")
-                txt.append("s_nop 0")
-                txt.append(f"v_mul_f32 {vr(SCR)}, {vr(SCR)}, {vr(ALPHA)}")
-                txt.append("s_nop 0")
-                txt.append(f"v_accvgpr_write_b32 {ar(base + i)}, {vr(SCR)}")
+        for base in range(A_O(qb, 0), A_O(qb, 0) + 64, 8):
+            txt += [f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, {ar(base + i)}" for i in range(8)]
+            txt += [f"v_pk_mul_f32 {vr(TMP + 4 + i, 2)}, {vr(TMP + 4 + i, 2)}, {vr(ALPHA, 2)} op_sel_hi:[1,0]" for i in range(0, 8, 2)]
+            txt += [f"v_accvgpr_write_b32 {ar(base + i)}, {vr(TMP + 4 + i)}" for i in range(8)]
     txt += ["s_nop 4", f"{skip}:"]
     it.append(("raw", "\n\t".join(txt)))
     for qb in range(2):
@@ -235,6 +248,13 @@ def mix(a, b):
 def phase(mfmas, others):
     """emit `mfmas` with `others` spread evenly behind them; LDS waits are derived from the tracker"""
     tags = phase.tags
+    if "nomfma" in ABL:
+        mfmas = []
+    if "nolds" in ABL:
+        for it in others:
+            if it[0] == "lds":
+                tags[it[2]] = -1
+        others = [it for it in others if it[0] != "lds"]
     n = max(1, len(mfmas))
     per = [len(others) * (i + 1) // n - len(others) * i // n for i in range(n)] if mfmas else []
     oi = 0
@@ -265,8 +285,10 @@ def phase(mfmas, others):
 phase.tags = {}
 
 
-def dma(srd, soff_sreg, slot_sreg):
+def dma(srd, soff_sreg, slot_sreg, prologue=False):
     """this wave's four 1 KiB pieces of a K or V tile: global -> LDS, range-checked, swizzle on the source"""
+    if "nodma" in ABL and not prologue:
+        return
     for i in range(4):
         e(f"s_add_u32 s{STMP2}, s{slot_sreg}, {LDS_WAVE}")
         if i:
@@ -290,7 +312,8 @@ def body(last):
     lds.reset(8)
     phase.tags = {("k", s): s for s in range(8)}
     e("s_waitcnt vmcnt(0)")
-    e("s_barrier")
+    if "nobarrier" not in ABL:
+        e("s_barrier")
     if not last:
         # request K(min(t+2, nt-1)) and V(min(t+1, nt-1))
         e(f"s_add_u32 s{STMP}, s{ST}, 2")
@@ -341,6 +364,10 @@ def main():
     e(f"s_mov_b32 s{C2 + 1}, {CSCALE}")
     e(f"s_xor_b32 s{NEGC}, {CSCALE}, 0x80000000")
     e(f"v_mov_b32 {vr(NEG)}, 0xf149f2ca")          # -1e30
+    e(f"v_mov_b32 {THR}, {CSCALE}")
+    e(f"v_rcp_f32 {THR}, {THR}")
+    e("s_nop 1")
+    e(f"v_mul_f32 {THR}, 0x41000000, {THR}")        # 8 / c
     for qb in range(2):
         e(f"v_mov_b32 {vr(MRUN[qb])}, {vr(NEG)}")
         e(f"v_mov_b32 {vr(L2[qb])}, 0")
@@ -375,11 +402,11 @@ def main():
         e(f"v_accvgpr_write_b32 {ar(i)}, 0")
     e("; ---- first tiles: K(0), K(1), V(0)")
     e(f"s_mov_b32 s{SOFFK}, 0")
-    dma(K_SRD, SOFFK, KS_CUR)
-    dma(V_SRD, SOFFK, VS_CUR)
+    dma(K_SRD, SOFFK, KS_CUR, True)
+    dma(V_SRD, SOFFK, VS_CUR, True)
     e(f"s_min_u32 s{STMP}, s{NTM1}, 1")
     e(f"s_mul_i32 s{SOFFK}, s{STMP}, {TILE_BYTES}")
-    dma(K_SRD, SOFFK, KS_NEXT)
+    dma(K_SRD, SOFFK, KS_NEXT, True)
     e("s_waitcnt vmcnt(0)")
     for i in range(64):
         e(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(S[0] + i)}")
@@ -434,12 +461,13 @@ def main():
     clob_v = ", ".join(f'"v{i}"' for i in range(1, 256))
     clob_a = ", ".join(f'"a{i}"' for i in range(0, 192))
     clob_s = ", ".join(f'"s{i}"' for i in range(60, 80))
-    with open(OUT, "w") as f:
+    path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
+    with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_attention_r64.py -- do not edit; see that file for the design.\n")
         f.write(f"#define SF_R64_N_PARAM {N_PARAM}\n")
         f.write("#define SF_R64_ASM_BODY \\\n" + body_txt.replace("\n", " \\\n") + "\n")
         f.write(f"#define SF_R64_CLOBBERS {clob_v}, {clob_a}, {clob_s}, \"vcc\", \"scc\", \"memory\"\n")
-    print(f"wrote {OUT}: {len(out)} asm lines")
+    print(f"wrote {path}: {len(out)} asm lines")
 
 
 if __name__ == "__main__":
