@@ -645,7 +645,7 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
 // addresses (same layouts and formulas as the kernels above) and hands them to the generated assembly
 // body through LDS; tools/gen_attention_r64.py documents the register map and the pipeline.
 constexpr int QT64 = 256;                      // 4 waves x 64 rows
-constexpr int ATT64_LDS = 5 * TILE_B;          // K ring of 3 + V ring of 2 = 80 KiB
+constexpr int ATT64_LDS = 7 * TILE_B;          // K ring of 4 + V ring of 3 = 112 KiB
 
 __global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

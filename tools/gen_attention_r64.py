@@ -2,35 +2,45 @@
 """Generator of the hand-scheduled 64-query-rows-per-wave attention kernel body for gfx950.
 
 Writes self-forcing_amd/csrc/attention_r64_asm.inc: ONE inline-asm string, the whole kernel after the
-C++ prologue of attention_r64.hip (which computes the per-lane addresses with the same formulas as the
-other attention kernels and hands them over through LDS).  Run it again after editing; the .inc is
-committed so that the build needs no Python.
+C++ prologue of `attention_r64_kernel` in attention.hip (which computes the per-lane addresses with the
+same formulas as the other attention kernels and hands them over through LDS).  Run it again after
+editing; the .inc is committed so that the build needs no Python.
 
-Why assembly: with 64 query rows per wave every K / V^T fragment read from LDS feeds TWO MFMAs
-(19 instead of 34 LDS bytes per kflop -- the measured limiter of the 32-row kernels), but the wave then
-needs all 512 registers (O^T in AGPRs, one wave per SIMD), and softmax VALU, LDS reads and MFMAs have to
-be interleaved by hand inside the single instruction stream; hipcc's allocator/scheduler does not
-produce that.
+Why assembly: with 64 query rows per wave every K / V^T fragment read from LDS feeds TWO MFMAs (19 instead
+of 34 LDS bytes per kflop -- the measured limiter of the 32-row kernels), but the wave then needs all 512
+registers (one wave per SIMD) and its softmax VALU, LDS reads, LDS-DMA requests and MFMAs share ONE
+in-order instruction stream: the matrix pipe stays busy only if no more than ~28 cycles of other
+instructions sit between two MFMAs (tools/probes/overlap_probe.hip), which hipcc's scheduler does not
+arrange.  Everything here is about taking instructions out of that stream and spreading the rest evenly:
 
-Per wave: 64 queries = two 32-query blocks A, B (MFMA 32x32x16 column blocks).  Keys in tiles of 64 =
-two 32-key units.  Registers:
-  AGPR  a[0:127]   O^T accumulators  O[qb][db]   (qb 0..1, db 0..3: 32 head dims each)
-        a[128:191] Q^T fragments     Q[qb][s]    (s 0..7: 16 head dims each)
-  VGPR  S0, S1     S^T accumulators of the unit being produced / consumed (2 x 32)
-        P0, P1     bf16 P^T fragments (2 x 16)
-        KF, VF     K and V^T fragment slots (8 x 4 each)
-Pipeline per tile t (units u0 = 2t, u1 = 2t+1), one s_barrier per tile, K ring of 3 slots, V ring of 2:
-  0  wait own LDS-DMA, barrier (K(t+1), V(t) landed); request K(t+2), V(t+1)
-  A  QK(u1) -> S1      ||  softmax(u0): S0 -> P0   ||  read V^T fragments of u0
-  B  PV(u0)            ||  read K fragments of unit 0 of tile t+1
-  C  QK(2t+2) -> S0    ||  softmax(u1): S1 -> P1   ||  read V^T fragments of u1
-  D  PV(u1)            ||  read K fragments of unit 1 of tile t+1
-The last tile runs the masked softmax (keys >= Lk -> -1e30) and drops the QK / K reads of tile t+1.
+  * the query block is pre-scaled by c = log2(e)/sqrt(d), and the QK^T accumulation STARTS from -m c (a
+    16-register tuple per query block, rewritten only on a rescale) instead of 0: the MFMA delivers
+    s c - m c directly, the softmax is exp2 + convert, no multiply / subtract pass;
+  * lazy rescale: m is only a reference point, so O and l are rescaled only when a row's maximum exceeds
+    it by more than 8 (in log2 units; P <= 2^8).  With O in AGPRs a rescale costs ~400 instructions; the
+    exact policy fired in most tiles (any of 128 rows seeing a new maximum) and cost 40 % of the kernel;
+  * row maxima and row sums run under the P.V MFMAs, exp2 + convert under the QK^T MFMAs;
+  * K / V^T fragments are read from LDS straight into AGPRs (MFMA A operands), Q^T lives in AGPRs too.
+
+Per wave: 64 queries = two 32-query blocks (MFMA 32x32x16 column blocks).  Keys in tiles of 64 = two
+32-key units.  Registers:
+  AGPR  a[0:127] O^T accumulators O[qb][db] | a[128:191] Q^T fragments Q[qb][s] | a[192:223] K fragments
+        | a[224:255] V^T fragments
+  VGPR  S0, S1 (2 x 32) scores of the unit being produced / consumed; P (16) bf16 P^T fragments;
+        MINIT (2 x 16) = -m c broadcast; state m c, l (pairs), row maxima
+Pipeline per tile t (units u0 = 2t, u1 = 2t+1); one s_barrier per tile; K ring of 4 slots, V ring of 3:
+  0  s_waitcnt vmcnt(4), barrier                      (everything but the latest V request has landed)
+  A  [rescale check u0]  QK(u1) -> S1  ||  exp2 / convert of S0 -> P  ||  read V^T fragments of u0
+  B  PV(u0)  ||  row sums of S0, row maxima of S1  ||  read K fragments of unit 0 of tile t+1  ||  request K(t+3)
+  C  [rescale check u1]  QK(2t+2) -> S0  ||  exp2 / convert of S1 -> P  ||  read V^T fragments of u1
+  D  PV(u1)  ||  row sums of S1, row maxima of S0  ||  read K fragments of unit 1 of tile t+1  ||  request V(t+2)
+The last tile runs with the key mask (keys >= Lk -> -1e30) and without successor work; the tile before it
+takes the maxima of the last tile's first unit with the mask.
 """
 import os
 import sys
 
-ABL = set()          # timing-only ablations: nosoftmax, nolds, nomfma, nodma, nobarrier, norescale
+ABL = set()          # timing-only ablations: nosoftmax, nolds, nomfma, nodma, nobarrier
 if "--abl" in sys.argv:
     ABL = set(sys.argv[sys.argv.index("--abl") + 1].split(","))
 
@@ -39,7 +49,6 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 # ---- inline-asm operands (inputs only)
 K_SRD, V_SRD, TILE_BYTES, NTILES, LK, CSCALE, LDS_WAVE, TID4, LDS_BASE = "%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8"
-THR = "v21"   # lazy-rescale threshold 8 / c, computed in the prologue
 
 # ---- register map
 KADDR = [1 + i for i in range(8)]
@@ -53,23 +62,23 @@ KCUR = [33 + i for i in range(8)]
 VCURLO = [41 + i for i in range(4)]
 VCURHI = [45 + i for i in range(4)]
 S = [64, 96]          # S[buf] + qb*16
-P = [128, 144]        # P[buf] + qb*8 + ks*4
-KF, VF = 160, 192
-TMP = 224
+P = 128               # P + qb*8 + ks*4
+MINIT = [144, 160]
+TMP = 176             # 24 scratch registers
 MX = [240, 241]
-MRUN = [242, 243]
+MRC = [242, 243]      # m c per query block (log2 units)
 L2 = [244, 246]
-MC = [248, 250]
-ALPHA = 252
+DLT = [248, 250]      # rescale amount
 NEG = 254
-SCR = 255
 A_O = lambda qb, db: (qb * 4 + db) * 16          # noqa: E731
 A_Q = lambda qb, s: 128 + (qb * 8 + s) * 4       # noqa: E731
+KF, VF = 192, 224     # AGPR fragment slots
 N_PARAM = 31
 
-ST, NTM1, KS_CUR, KS_NEXT, KS_DMA, VS_CUR, VS_DMA, STMP = 60, 61, 62, 63, 64, 65, 66, 67
-C2, NEGC, SVCC, SEXEC, SOFFK, SOFFV, SLIM, STMP2 = 68, 70, 72, 74, 76, 77, 78, 79
-K_RING, V_BASE = 3 * 16384, 3 * 16384
+ST, NTM1, KS_CUR, KS_N1, KS_N2, KS_DMA, VS_CUR, VS_N1, VS_DMA, STMP = 60, 61, 62, 63, 64, 65, 66, 67, 68, 69
+C2, SEXEC, SOFFK, SOFFV, SLIM, STMP2 = 70, 72, 74, 75, 76, 77
+V_BASE = 4 * 16384
+THR = "0x41000000"    # 8.0
 
 out = []
 
@@ -103,7 +112,8 @@ class Lds:
             return
         after = self.issued - 1 - idx
         e(f"s_waitcnt lgkmcnt({min(after, 15)})")
-        self.done = max(self.done, idx + 1) if after <= 15 else self.done
+        if after <= 15:
+            self.done = max(self.done, idx + 1)
 
     def reset(self, in_flight):
         self.issued, self.done = in_flight, 0
@@ -113,39 +123,41 @@ lds = Lds()
 
 
 def k_reads(kb):
-    """the 8 K fragments (one per 16-wide head-dim step) of a 32-key unit -> KF slots"""
-    return [("lds", f"ds_read_b128 {vr(KF + 4 * s, 4)}, {vr(KCUR[s])} offset:{kb * 8192}", ("k", s)) for s in range(8)]
+    """the 8 K fragments (one per 16-wide head-dim step) of a 32-key unit -> AGPR slots"""
+    return [("lds", f"ds_read_b128 {ar(KF + 4 * s, 4)}, {vr(KCUR[s])} offset:{kb * 8192}", ("k", s)) for s in range(8)]
 
 
 def v_reads(kb):
-    """the 8 V^T fragments (2 key steps x 4 head-dim blocks) of a 32-key unit -> VF slots (lo, hi halves)"""
+    """the 8 V^T fragments (2 key steps x 4 head-dim blocks) of a 32-key unit -> AGPR slots (lo, hi halves)"""
     r = []
     for ks in range(2):
         for db in range(4):
             f = ks * 4 + db
             off = (2 * kb + ks) * 4096
-            r.append(("lds", f"ds_read_b64_tr_b16 {vr(VF + 4 * f, 2)}, {vr(VCURLO[db])} offset:{off}", ("vlo", f)))
-            r.append(("lds", f"ds_read_b64_tr_b16 {vr(VF + 4 * f + 2, 2)}, {vr(VCURHI[db])} offset:{off}", ("vhi", f)))
+            r.append(("lds", f"ds_read_b64_tr_b16 {ar(VF + 4 * f, 2)}, {vr(VCURLO[db])} offset:{off}", ("vlo", f)))
+            r.append(("lds", f"ds_read_b64_tr_b16 {ar(VF + 4 * f + 2, 2)}, {vr(VCURHI[db])} offset:{off}", ("vhi", f)))
     return r
 
 
-def qk_mfmas(sbuf):
+def qk_mfmas(sbuf, zero_init=False):
+    """S^T = K Q^T + (-m c): the accumulation starts from the MINIT tuple"""
     m = []
     for s in range(8):
         for qb in range(2):
             acc = vr(S[sbuf] + 16 * qb, 16)
-            m.append((f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(KF + 4 * s, 4)}, {ar(A_Q(qb, s), 4)}, {'0' if s == 0 else acc}", [("k", s)]))
+            src_c = acc if s else ("0" if zero_init else vr(MINIT[qb], 16))
+            m.append((f"v_mfma_f32_32x32x16_bf16 {acc}, {ar(KF + 4 * s, 4)}, {ar(A_Q(qb, s), 4)}, {src_c}", [("k", s)]))
     return m
 
 
-def pv_mfmas(pbuf):
+def pv_mfmas():
     m = []
     for ks in range(2):
         for db in range(4):
             f = ks * 4 + db
             for qb in range(2):
                 acc = ar(A_O(qb, db), 16)
-                m.append((f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(VF + 4 * f, 4)}, {vr(P[pbuf] + 8 * qb + 4 * ks, 4)}, {acc}", [("vlo", f), ("vhi", f)]))
+                m.append((f"v_mfma_f32_32x32x16_bf16 {acc}, {ar(VF + 4 * f, 4)}, {vr(P + 8 * qb + 4 * ks, 4)}, {acc}", [("vlo", f), ("vhi", f)]))
     return m
 
 
@@ -157,20 +169,14 @@ def new_label(stem):
     return f".Lr64_{stem}_{label_n[0]}%="
 
 
-def softmax_items(sbuf, pbuf, masked, kb):
-    """VALU stream of one unit's online softmax for both query blocks; ("raw", text) items may be
-    control flow (the rare O rescale), everything else is one instruction per item."""
+def max_items(sbuf, masked, kb):
+    """row maxima of one unit's scores (already s c - m c) for both query blocks -> MX"""
     it = []
     sreg = lambda qb, r: S[sbuf] + 16 * qb + r   # noqa: E731
     if "nosoftmax" in ABL:
-        for r in range(0, 16, 2):
-            for qb in range(2):
-                dst = P[pbuf] + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1)
-                it.append(("valu", f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(sreg(qb, r))}, {vr(sreg(qb, r + 1))}"))
-        it.append(("valu", "s_nop 1"))
         return it
     if masked:
-        # keys of this unit at or past Lk: key = 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 hh ; SLIM = Lk - 64 t
+        # key = 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 hh ; SLIM = Lk - 64 t
         for r in range(16):
             it.append(("valu", f"s_sub_i32 s{STMP}, s{SLIM}, {32 * kb + (r & 3) + 8 * (r >> 2)}"))
             it.append(("valu", f"v_cmp_le_i32 vcc, s{STMP}, {vr(HH4)}"))
@@ -189,46 +195,64 @@ def softmax_items(sbuf, pbuf, masked, kb):
         it.append(("valu", f"s_nop 0\n\tv_permlane32_swap_b32 {vr(MX[qb])}, {vr(TMP + qb)}"))
     for qb in range(2):
         it.append(("valu", f"s_nop 0\n\tv_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(TMP + qb)}"))
-    # Lazy rescale: the running maximum m is only a reference point -- exp2((s - m) c) stays exact for any
-    # m as long as it does not overflow -- so O and l are rescaled only when some row's maximum has grown
-    # by more than THR = 8 / c (P <= 2^8, harmless in bf16 / fp32).  With O in AGPRs a rescale costs
-    # ~330 instructions; the exact policy (rescale whenever any of the wave's 128 rows sees a new maximum)
-    # fired in most tiles and cost 40 % of the kernel.
+    return it
+
+
+def rescale_check(sbuf):
+    """emitted in front of a QK phase: if some row of this unit exceeds its reference by more than 2^8,
+    move the reference: m c += d, l *= 2^-d, O *= 2^-d, this unit's scores -= d, MINIT -= d  (d = max(mx, 0))"""
+    if "nosoftmax" in ABL:
+        return
     skip = new_label("norescale")
-    txt = [f"v_sub_f32 {vr(TMP + 2)}, {vr(MX[0])}, {vr(MRUN[0])}", f"v_sub_f32 {vr(TMP + 3)}, {vr(MX[1])}, {vr(MRUN[1])}",
-           f"v_max_f32 {vr(TMP + 2)}, {vr(TMP + 2)}, {vr(TMP + 3)}",
-           f"v_cmp_lt_f32 vcc, {THR}, {vr(TMP + 2)}", "s_nop 1", f"s_cbranch_vccz {skip}"]
+    e(f"v_max_f32 {vr(TMP + 2)}, {vr(MX[0])}, {vr(MX[1])}")
+    e(f"v_cmp_lt_f32 vcc, {THR}, {vr(TMP + 2)}")
+    e("s_nop 1")
+    e(f"s_cbranch_vccz {skip}")
     for qb in range(2):
-        txt += [f"v_max_f32 {vr(TMP + 2)}, {vr(MRUN[qb])}, {vr(MX[qb])}",
-                f"v_sub_f32 {vr(TMP + 3)}, {vr(MRUN[qb])}, {vr(TMP + 2)}",
-                f"v_mov_b32 {vr(MRUN[qb])}, {vr(TMP + 2)}",
-                f"v_mul_f32 {vr(TMP + 3)}, s{C2}, {vr(TMP + 3)}",
-                f"v_exp_f32 {vr(ALPHA)}, {vr(TMP + 3)}", "s_nop 1",
-                f"v_pk_mul_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(ALPHA, 2)} op_sel_hi:[1,0]"]
+        d = DLT[qb]
+        e(f"v_max_f32 {vr(d)}, 0, {vr(MX[qb])}")
+        e(f"v_add_f32 {vr(MRC[qb])}, {vr(MRC[qb])}, {vr(d)}")
+        e(f"v_exp_f32 {vr(TMP + 2)}, -{vr(d)}")
+        e("s_nop 1")
+        e(f"v_mov_b32 {vr(TMP + 3)}, {vr(TMP + 2)}")
+        e(f"v_pk_mul_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(TMP + 2, 2)}")
         for base in range(A_O(qb, 0), A_O(qb, 0) + 64, 8):
-            txt += [f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, {ar(base + i)}" for i in range(8)]
-            txt += [f"v_pk_mul_f32 {vr(TMP + 4 + i, 2)}, {vr(TMP + 4 + i, 2)}, {vr(ALPHA, 2)} op_sel_hi:[1,0]" for i in range(0, 8, 2)]
-            txt += [f"v_accvgpr_write_b32 {ar(base + i)}, {vr(TMP + 4 + i)}" for i in range(8)]
-    txt += ["s_nop 4", f"{skip}:"]
-    it.append(("raw", "\n\t".join(txt)))
-    for qb in range(2):
-        it.append(("valu", f"v_mul_f32 {vr(MC[qb])}, s{NEGC}, {vr(MRUN[qb])}"))
-    for r in range(0, 16, 2):
-        for qb in range(2):
-            x = vr(sreg(qb, r), 2)
-            it.append(("valu", f"v_pk_fma_f32 {x}, {x}, s[{C2}:{C2 + 1}], {vr(MC[qb], 2)} op_sel_hi:[1,1,0]"))
-    for r in range(16):
-        for qb in range(2):
-            it.append(("valu", f"v_exp_f32 {vr(sreg(qb, r))}, {vr(sreg(qb, r))}"))
-    for r in range(0, 16, 2):
-        for qb in range(2):
-            it.append(("valu", f"v_pk_add_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(sreg(qb, r), 2)}"))
+            for i in range(8):
+                e(f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, {ar(base + i)}")
+            for i in range(0, 8, 2):
+                e(f"v_pk_mul_f32 {vr(TMP + 4 + i, 2)}, {vr(TMP + 4 + i, 2)}, {vr(TMP + 2, 2)}")
+            for i in range(8):
+                e(f"v_accvgpr_write_b32 {ar(base + i)}, {vr(TMP + 4 + i)}")
+        for r in range(16):
+            e(f"v_sub_f32 {vr(S[sbuf] + 16 * qb + r)}, {vr(S[sbuf] + 16 * qb + r)}, {vr(d)}")
+        for r in range(16):
+            e(f"v_sub_f32 {vr(MINIT[qb] + r)}, {vr(MINIT[qb] + r)}, {vr(d)}")
+    e("s_nop 4")
+    e(f"{skip}:")
+
+
+def exp_items(sbuf):
+    """p = exp2(s c - m c) in place, then the bf16 P^T fragments"""
+    it = []
+    sreg = lambda qb, r: S[sbuf] + 16 * qb + r   # noqa: E731
+    if "nosoftmax" not in ABL:
+        for r in range(16):
+            for qb in range(2):
+                it.append(("valu", f"v_exp_f32 {vr(sreg(qb, r))}, {vr(sreg(qb, r))}"))
     for r in range(0, 16, 2):   # P^T fragment of key step ks = r >> 3, element pair (r & 7) >> 1
         for qb in range(2):
-            dst = P[pbuf] + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1)
+            dst = P + 8 * qb + 4 * (r >> 3) + ((r & 7) >> 1)
             it.append(("valu", f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(sreg(qb, r))}, {vr(sreg(qb, r + 1))}"))
     it.append(("valu", "s_nop 1"))
     return it
+
+
+def sum_items(sbuf):
+    """row sums of the p values left in S[sbuf] (done under the P.V MFMAs)"""
+    if "nosoftmax" in ABL:
+        return []
+    return [("valu", f"v_pk_add_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(S[sbuf] + 16 * qb + r, 2)}")
+            for r in range(0, 16, 2) for qb in range(2)]
 
 
 def mix(a, b):
@@ -260,8 +284,7 @@ def phase(mfmas, others):
     oi = 0
 
     def emit_other(item):
-        kind = item[0]
-        if kind == "lds":
+        if item[0] == "lds":
             tags[item[2]] = lds.read(item[1])
         else:
             e(item[1])
@@ -285,17 +308,21 @@ def phase(mfmas, others):
 phase.tags = {}
 
 
-def dma(srd, soff_sreg, slot_sreg, prologue=False):
+def dma_items(srd, soff_sreg, slot_sreg, prologue=False):
     """this wave's four 1 KiB pieces of a K or V tile: global -> LDS, range-checked, swizzle on the source"""
     if "nodma" in ABL and not prologue:
-        return
+        return []
+    it = []
     for i in range(4):
-        e(f"s_add_u32 s{STMP2}, s{slot_sreg}, {LDS_WAVE}")
-        if i:
-            e(f"s_add_u32 s{STMP2}, s{STMP2}, {i * 1024}")
-        e(f"s_mov_b32 m0, s{STMP2}")
-        e("s_nop 2")
-        e(f"buffer_load_dwordx4 {vr(DMAOFF[i])}, {srd}, s{soff_sreg} offen lds")
+        txt = [f"s_add_u32 s{STMP2}, s{slot_sreg}, {LDS_WAVE}", f"s_add_u32 m0, s{STMP2}, {i * 1024}", "s_nop 1",
+               f"buffer_load_dwordx4 {vr(DMAOFF[i])}, {srd}, s{soff_sreg} offen lds"]
+        it.append(("raw", "\n\t".join(txt)))
+    return it
+
+
+def dma(srd, soff_sreg, slot_sreg, prologue=False):
+    for _, t in dma_items(srd, soff_sreg, slot_sreg, prologue):
+        e(t)
 
 
 def set_kcur(slot_sreg):
@@ -307,42 +334,56 @@ def set_vcur(slot_sreg):
             + [("valu", f"v_add_u32 {vr(VCURHI[d])}, s{slot_sreg}, {vr(VHI[d])}") for d in range(4)])
 
 
-def body(last):
-    # in flight at entry: the 8 K fragment reads of unit 1 of tile t (issued by the previous phase D / prologue)
+def clamp_tile(dst_sreg, ahead):
+    e(f"s_add_u32 s{STMP}, s{ST}, {ahead}")
+    e(f"s_min_u32 s{STMP}, s{STMP}, s{NTM1}")
+    e(f"s_mul_i32 s{dst_sreg}, s{STMP}, {TILE_BYTES}")
+
+
+def body(kind):
+    """one key tile; kind: 'normal', 'penult' (the next tile is the last one: its first unit's maxima are
+    taken with the key mask) or 'last' (masked, no successor)"""
+    last = kind == "last"
+    # in flight at entry: the 8 K fragment reads of unit 1 of tile t (issued by the previous phase D / prologue);
+    # MX holds the row maxima of unit 0 (taken in the previous phase D / prologue)
     lds.reset(8)
     phase.tags = {("k", s): s for s in range(8)}
-    e("s_waitcnt vmcnt(0)")
+    e("s_waitcnt vmcnt(4)" if kind == "normal" else "s_waitcnt vmcnt(0)")
     if "nobarrier" not in ABL:
         e("s_barrier")
+    dma_k = dma_v = []
     if not last:
-        # request K(min(t+2, nt-1)) and V(min(t+1, nt-1))
-        e(f"s_add_u32 s{STMP}, s{ST}, 2")
-        e(f"s_min_u32 s{STMP}, s{STMP}, s{NTM1}")
-        e(f"s_mul_i32 s{SOFFK}, s{STMP}, {TILE_BYTES}")
+        clamp_tile(SOFFK, 3)
+        clamp_tile(SOFFV, 2)
+        dma_k, dma_v = dma_items(K_SRD, SOFFK, KS_DMA), dma_items(V_SRD, SOFFV, VS_DMA)
+    if kind == "penult":
         e(f"s_add_u32 s{STMP}, s{ST}, 1")
-        e(f"s_min_u32 s{STMP}, s{STMP}, s{NTM1}")
-        e(f"s_mul_i32 s{SOFFV}, s{STMP}, {TILE_BYTES}")
-        dma(K_SRD, SOFFK, KS_DMA)
-        dma(V_SRD, SOFFV, VS_DMA)
-    else:
+        e(f"s_lshl_b32 s{STMP}, s{STMP}, 6")
+        e(f"s_sub_i32 s{SLIM}, {LK}, s{STMP}")       # Lk - 64 (t+1)
+    if last:
         e(f"s_lshl_b32 s{STMP}, s{ST}, 6")
         e(f"s_sub_i32 s{SLIM}, {LK}, s{STMP}")
-    # A
-    phase(qk_mfmas(1), mix(softmax_items(0, 0, last, 0), v_reads(0)))
-    # B
-    phase(pv_mfmas(0), [] if last else set_kcur(KS_NEXT) + k_reads(0))
-    # C
-    phase([] if last else qk_mfmas(0), v_reads(1) + softmax_items(1, 1, last, 1) if last else mix(softmax_items(1, 1, last, 1), v_reads(1)))
-    # D
-    phase(pv_mfmas(1), [] if last else k_reads(1))
+    # A: QK(u1) -> S1 || exp2 / convert of u0 (S0 -> P) || V^T fragments of u0
+    rescale_check(0)
+    phase(qk_mfmas(1), mix(exp_items(0), v_reads(0)))
+    # B: PV(u0) || row sums of u0, row maxima of u1 || K fragments of unit 0 of tile t+1 || request K(t+3)
+    pad = [("valu", "s_nop 7"), ("valu", "s_nop 7")] if last else []
+    phase(pv_mfmas(), mix(sum_items(0) + ([] if last else set_kcur(KS_N1)) + pad + mix(max_items(1, last, 1), [] if last else k_reads(0)), dma_k))
+    # C: QK(2t+2) -> S0 || exp2 / convert of u1 (S1 -> P) || V^T fragments of u1
+    rescale_check(1)
+    phase([] if last else qk_mfmas(0), v_reads(1) + exp_items(1) if last else mix(exp_items(1), v_reads(1)))
+    # D: PV(u1) || row sums of u1, row maxima of unit 2t+2 || K fragments of unit 1 of tile t+1 || request V(t+2)
+    phase(pv_mfmas(), mix(sum_items(1) + ([] if last else mix(max_items(0, kind == "penult", 0), k_reads(1))), dma_v))
     if not last:
-        # rotate the rings: K (cur, next, dma) <- (next, dma, cur); V (cur, dma) swap
+        # rotate the rings: K (cur, n1, n2, dma) <- (n1, n2, dma, cur); V (cur, n1, dma) <- (n1, dma, cur)
         e(f"s_mov_b32 s{STMP}, s{KS_CUR}")
-        e(f"s_mov_b32 s{KS_CUR}, s{KS_NEXT}")
-        e(f"s_mov_b32 s{KS_NEXT}, s{KS_DMA}")
+        e(f"s_mov_b32 s{KS_CUR}, s{KS_N1}")
+        e(f"s_mov_b32 s{KS_N1}, s{KS_N2}")
+        e(f"s_mov_b32 s{KS_N2}, s{KS_DMA}")
         e(f"s_mov_b32 s{KS_DMA}, s{STMP}")
         e(f"s_mov_b32 s{STMP}, s{VS_CUR}")
-        e(f"s_mov_b32 s{VS_CUR}, s{VS_DMA}")
+        e(f"s_mov_b32 s{VS_CUR}, s{VS_N1}")
+        e(f"s_mov_b32 s{VS_N1}, s{VS_DMA}")
         e(f"s_mov_b32 s{VS_DMA}, s{STMP}")
         for _, t in set_vcur(VS_CUR):
             e(t)
@@ -362,74 +403,91 @@ def main():
     e("; ---- constants and state")
     e(f"s_mov_b32 s{C2}, {CSCALE}")
     e(f"s_mov_b32 s{C2 + 1}, {CSCALE}")
-    e(f"s_xor_b32 s{NEGC}, {CSCALE}, 0x80000000")
     e(f"v_mov_b32 {vr(NEG)}, 0xf149f2ca")          # -1e30
-    e(f"v_mov_b32 {THR}, {CSCALE}")
-    e(f"v_rcp_f32 {THR}, {THR}")
-    e("s_nop 1")
-    e(f"v_mul_f32 {THR}, 0x41000000, {THR}")        # 8 / c
     for qb in range(2):
-        e(f"v_mov_b32 {vr(MRUN[qb])}, {vr(NEG)}")
         e(f"v_mov_b32 {vr(L2[qb])}, 0")
         e(f"v_mov_b32 {vr(L2[qb] + 1)}, 0")
-        e(f"v_mov_b32 {vr(MC[qb] + 1)}, 0")
-    e(f"v_mov_b32 {vr(ALPHA + 1)}, 0")
     e(f"s_sub_u32 s{NTM1}, {NTILES}, 1")
     e(f"s_mov_b32 s{ST}, 0")
-    e(f"s_mov_b32 s{KS_CUR}, 0")
-    e(f"s_mov_b32 s{KS_NEXT}, 16384")
-    e(f"s_mov_b32 s{KS_DMA}, 32768")
-    e(f"s_mov_b32 s{VS_CUR}, {V_BASE}")
-    e(f"s_mov_b32 s{VS_DMA}, {V_BASE + 16384}")
-    e("; ---- zero the five LDS slots (rows past Lk are never fetched; 0 * stale NaN would poison P.V)")
-    e(f"v_mov_b32 {vr(TMP)}, 0")
-    e(f"v_mov_b32 {vr(TMP + 1)}, 0")
-    e(f"v_mov_b32 {vr(TMP + 2)}, 0")
-    e(f"v_mov_b32 {vr(TMP + 3)}, 0")
+    for i, sr in enumerate((KS_CUR, KS_N1, KS_N2, KS_DMA)):
+        e(f"s_mov_b32 s{sr}, {i * 16384}")
+    for i, sr in enumerate((VS_CUR, VS_N1, VS_DMA)):
+        e(f"s_mov_b32 s{sr}, {V_BASE + i * 16384}")
+    e("; ---- zero the seven LDS slots (rows past Lk are never fetched; 0 * stale NaN would poison P.V)")
+    for i in range(4):
+        e(f"v_mov_b32 {vr(TMP + i)}, 0")
     e(f"v_subrev_u32 {vr(TMP + 4)}, {LDS_BASE}, {TID4}")    # TID4 = lds base + tid*4
     e(f"v_lshlrev_b32 {vr(TMP + 4)}, 2, {vr(TMP + 4)}")
     e(f"v_add_u32 {vr(TMP + 4)}, {LDS_BASE}, {vr(TMP + 4)}")   # lds base + tid*16
-    e(f"v_add_u32 {vr(TMP + 5)}, 40960, {vr(TMP + 4)}")
-    for i in range(20):
-        e(f"ds_write_b128 {vr(TMP + 4 + i // 10)}, {vr(TMP, 4)} offset:{(i % 10) * 4096}")
+    e(f"v_add_u32 {vr(TMP + 5)}, 0x10000, {vr(TMP + 4)}")
+    for i in range(28):
+        e(f"ds_write_b128 {vr(TMP + 4 + i // 16)}, {vr(TMP, 4)} offset:{(i % 16) * 4096}")
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")
-    e("; ---- Q^T fragments -> AGPRs, O^T = 0")
+    e("; ---- first tiles: K(0), K(1), K(2), V(0), V(1) (tile indices clamped to the last tile)")
+    e(f"s_mov_b32 s{SOFFK}, 0")
+    dma(K_SRD, SOFFK, KS_CUR, True)
+    dma(V_SRD, SOFFK, VS_CUR, True)
+    clamp_tile(SOFFK, 1)
+    dma(K_SRD, SOFFK, KS_N1, True)
+    dma(V_SRD, SOFFK, VS_N1, True)
+    clamp_tile(SOFFK, 2)
+    dma(K_SRD, SOFFK, KS_N2, True)
+    e("; ---- Q^T fragments, scaled by c, -> AGPRs; O^T = 0")
     for qb in range(2):
         for s in range(8):
             e(f"global_load_dwordx4 {vr(S[0] + (qb * 8 + s) * 4, 4)}, {vr(QP[qb], 2)}, off offset:{s * 32}")
     for i in range(128):
         e(f"v_accvgpr_write_b32 {ar(i)}, 0")
-    e("; ---- first tiles: K(0), K(1), V(0)")
-    e(f"s_mov_b32 s{SOFFK}, 0")
-    dma(K_SRD, SOFFK, KS_CUR, True)
-    dma(V_SRD, SOFFK, VS_CUR, True)
-    e(f"s_min_u32 s{STMP}, s{NTM1}, 1")
-    e(f"s_mul_i32 s{SOFFK}, s{STMP}, {TILE_BYTES}")
-    dma(K_SRD, SOFFK, KS_NEXT, True)
     e("s_waitcnt vmcnt(0)")
     for i in range(64):
-        e(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(S[0] + i)}")
+        x = S[0] + i
+        e(f"v_lshlrev_b32 {vr(TMP)}, 16, {vr(x)}")
+        e(f"v_and_b32 {vr(TMP + 1)}, 0xffff0000, {vr(x)}")
+        e(f"v_pk_mul_f32 {vr(TMP, 2)}, {vr(TMP, 2)}, s[{C2}:{C2 + 1}]")
+        e(f"v_cvt_pk_bf16_f32 {vr(x)}, {vr(TMP)}, {vr(TMP + 1)}")
+        e(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(x)}")
     e("s_nop 4")
     e("s_barrier")
     for _, t in set_kcur(KS_CUR):
         e(t)
     for _, t in set_vcur(VS_CUR):
         e(t)
-    e("; ---- QK of unit 0, then the K fragments of unit 1 in flight for the loop")
+    e("; ---- QK of unit 0 from zero, K fragments of unit 1 in flight for the loop, first reference m = row max")
     lds.reset(0)
     phase.tags = {}
     phase([], k_reads(0))
-    phase(qk_mfmas(0), [])
+    phase(qk_mfmas(0, zero_init=True), [])
     phase([], k_reads(1))
-    loop, last_l = ".Lr64_loop%=", ".Lr64_last%="
+    e("s_nop 7")
+    e("s_nop 7")
+    e("s_nop 7")
+    e(f"s_mov_b32 s{SLIM}, {LK}")
+    for _, t in max_items(0, True, 0):
+        e(t)
+    for qb in range(2):
+        if "nosoftmax" in ABL:
+            e(f"v_mov_b32 {vr(MX[qb])}, 0")
+        e(f"v_mov_b32 {vr(MRC[qb])}, {vr(MX[qb])}")
+        for r in range(16):
+            e(f"v_sub_f32 {vr(MINIT[qb] + r)}, 0, {vr(MX[qb])}")
+        for r in range(16):
+            e(f"v_sub_f32 {vr(S[0] + 16 * qb + r)}, {vr(S[0] + 16 * qb + r)}, {vr(MX[qb])}")
+        e(f"v_mov_b32 {vr(MX[qb])}, 0")
+    e("s_nop 4")
+    loop, last_l, pen_l = ".Lr64_loop%=", ".Lr64_last%=", ".Lr64_penult%="
     e(f"{loop}:")
     e(f"s_cmp_eq_u32 s{ST}, s{NTM1}")
     e(f"s_cbranch_scc1 {last_l}")
-    body(False)
+    e(f"s_add_u32 s{STMP}, s{ST}, 1")
+    e(f"s_cmp_eq_u32 s{STMP}, s{NTM1}")
+    e(f"s_cbranch_scc1 {pen_l}")
+    body("normal")
     e(f"s_branch {loop}")
+    e(f"{pen_l}:")
+    body("penult")
     e(f"{last_l}:")
-    body(True)
+    body("last")
     e("; ---- epilogue: O / l -> bf16, rows past Lq masked off")
     e("s_nop 7")
     e("s_nop 7")
@@ -441,7 +499,7 @@ def main():
         e(f"v_permlane32_swap_b32 {vr(L2[qb])}, {vr(TMP)}")
         e("s_nop 0")
         e(f"v_add_f32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(TMP)}")
-        e(f"v_rcp_f32 {vr(ALPHA)}, {vr(L2[qb])}")
+        e(f"v_rcp_f32 {vr(DLT[0])}, {vr(L2[qb])}")
         e("s_nop 1")
         e(f"v_cmp_ne_u32 vcc, 0, {vr(VALID[qb])}")
         e(f"s_and_saveexec_b64 s[{SEXEC}:{SEXEC + 1}], vcc")
@@ -450,7 +508,7 @@ def main():
                 e(f"v_accvgpr_read_b32 {vr(S[0] + i)}, {ar(A_O(qb, db) + i)}")
             e("s_nop 1")
             for i in range(16):
-                e(f"v_mul_f32 {vr(S[0] + i)}, {vr(S[0] + i)}, {vr(ALPHA)}")
+                e(f"v_mul_f32 {vr(S[0] + i)}, {vr(S[0] + i)}, {vr(DLT[0])}")
             for i in range(8):
                 e(f"v_cvt_pk_bf16_f32 {vr(S[1] + i)}, {vr(S[0] + 2 * i)}, {vr(S[0] + 2 * i + 1)}")
             for rg in range(4):
@@ -459,7 +517,7 @@ def main():
         e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
     body_txt = "\n".join('    "' + ln.replace("\n\t", '\\n\\t') + '\\n"' for ln in out)
     clob_v = ", ".join(f'"v{i}"' for i in range(1, 256))
-    clob_a = ", ".join(f'"a{i}"' for i in range(0, 192))
+    clob_a = ", ".join(f'"a{i}"' for i in range(0, 256))
     clob_s = ", ".join(f'"s{i}"' for i in range(60, 80))
     path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
     with open(path, "w") as f:
