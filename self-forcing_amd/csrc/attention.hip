@@ -745,9 +745,13 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
   // 256-row / 8-wave structure when it fills most of the chip's 256 CUs in whole rounds, else
   // 128-row / 4-wave workgroups (two per CU)
-  if (getenv("SF_ATTN_R64")) {   // A/B switch while the hand-scheduled kernel is being brought up
+  // Structure: long key sequences that fill the chip run the hand-scheduled 64-rows-per-wave kernel;
+  // short ones (cross-attention: 8 key tiles) the 8-wave anti-phase kernel; small problems the 4-wave one.
+  // Environment switches (A/B timing and tests only): SF_ATTN_R64 / SF_ATTN_W8 / SF_ATTN_W4 force a structure.
+  const long nwg64 = (long)((Lq + QT64 - 1) / QT64) * H * B;
+  const bool forced = getenv("SF_ATTN_W8") || getenv("SF_ATTN_W4");
+  if (getenv("SF_ATTN_R64") || (!forced && nwg64 >= 192 && Lk > 1024)) {
     p.q_tiles = (Lq + QT64 - 1) / QT64;
-    const long nwg64 = (long)p.q_tiles * H * B;
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);

@@ -132,9 +132,40 @@ def test_attention_w8_structure(B, H, Lq, Lk):
     assert rel(out, ref) < 6e-3
 
 
-@pytest.mark.parametrize("force", ["SF_ATTN_W8", "SF_ATTN_W4"])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 12, 4200, 1100), (2, 8, 3100, 1300), (1, 12, 4680, 4680), (1, 16, 3073, 2049)])
+def test_attention_r64_structure(B, H, Lq, Lk):
+    """Long key sequences that fill the chip dispatch the hand-scheduled 64-rows-per-wave kernel."""
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g), bf((B, Lk, H, 128), g)
+    ref = wo.sdpa(q.float(), k.float(), v.float())
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert rel(out, ref) < 6e-3
+
+
+def test_attention_r64_lazy_rescale_and_stale_lds(monkeypatch):
+    """The 64-row kernel moves its softmax reference only when a row's maximum exceeds it by 2^8: feed it
+    scores that (a) stay inside the threshold, (b) jump far beyond it late in the sequence, (c) decay, and
+    rows whose large early maximum makes every later probability underflow; NaN left in LDS by a previous
+    launch must not leak into rows past Lk."""
+    monkeypatch.setenv("SF_ATTN_R64", "1")
+    g = torch.Generator().manual_seed(21)
+    B, H, Lq, Lk = 1, 2, 200, 1000
+    q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g, 0.2), bf((B, Lk, H, 128), g)
+    k[0, 900, 0] = (q[0, 5, 0].float() * 4).to(torch.bfloat16)      # +hundreds of log2 units at tile 14
+    k[0, 2, 1] = (q[0, 9, 1].float() * 4).to(torch.bfloat16)        # dominant key in the first tile
+    k[0, 500, 0] = (q[0, 70, 0].float() * 0.6).to(torch.bfloat16)   # moderate bump (inside / near the threshold)
+    ref = wo.sdpa(q.float(), k.float(), v.float())
+    nan = torch.full((1, 64, 2, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention(nan, nan, nan)                                     # leaves NaN bit patterns in LDS
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    assert torch.isfinite(out.float()).all()
+    assert rel(out, ref) < 6e-3
+    assert (out.float().cpu() - ref).abs().max() < 4e-2
+
+
+@pytest.mark.parametrize("force", ["SF_ATTN_W8", "SF_ATTN_W4", "SF_ATTN_R64"])
 def test_attention_both_structures_small_and_spiky(force, monkeypatch):
-    """Both kernels on the same ragged inputs incl. a late max spike (rescale branch) and Lk = 1."""
+    """All kernels on the same ragged inputs incl. a late max spike (rescale branch) and Lk = 1."""
     monkeypatch.setenv(force, "1")
     g = torch.Generator().manual_seed(5)
     for (B, H, Lq, Lk) in [(1, 2, 300, 448), (2, 1, 33, 65), (1, 3, 257, 1), (1, 1, 512, 129)]:

@@ -111,7 +111,8 @@ class Lds:
         if idx < self.done or idx < 0:
             return
         after = self.issued - 1 - idx
-        e(f"s_waitcnt lgkmcnt({min(after, 15)})")
+        if "nowait" not in ABL:
+            e(f"s_waitcnt lgkmcnt({min(after, 15)})")
         if after <= 15:
             self.done = max(self.done, idx + 1)
 
@@ -162,6 +163,7 @@ def pv_mfmas():
 
 
 label_n = [0]
+cold = []     # out-of-line blocks (the rare rescale), emitted behind the kernel's last instruction
 
 
 def new_label(stem):
@@ -173,7 +175,7 @@ def max_items(sbuf, masked, kb):
     """row maxima of one unit's scores (already s c - m c) for both query blocks -> MX"""
     it = []
     sreg = lambda qb, r: S[sbuf] + 16 * qb + r   # noqa: E731
-    if "nosoftmax" in ABL:
+    if "nosoftmax" in ABL or "nomax" in ABL:
         return it
     if masked:
         # key = 64 t + 32 kb + (r&3) + 8 (r>>2) + 4 hh ; SLIM = Lk - 64 t
@@ -203,39 +205,41 @@ def rescale_check(sbuf):
     move the reference: m c += d, l *= 2^-d, O *= 2^-d, this unit's scores -= d, MINIT -= d  (d = max(mx, 0))"""
     if "nosoftmax" in ABL:
         return
-    skip = new_label("norescale")
+    blk, back = new_label("rescale"), new_label("rescaled")
     e(f"v_max_f32 {vr(TMP + 2)}, {vr(MX[0])}, {vr(MX[1])}")
     e(f"v_cmp_lt_f32 vcc, {THR}, {vr(TMP + 2)}")
     e("s_nop 1")
-    e(f"s_cbranch_vccz {skip}")
+    e(f"s_cbranch_vccnz {blk}")      # rare: the common path falls through
+    e(f"{back}:")
+    c = [f"{blk}:"]
     for qb in range(2):
         d = DLT[qb]
-        e(f"v_max_f32 {vr(d)}, 0, {vr(MX[qb])}")
-        e(f"v_add_f32 {vr(MRC[qb])}, {vr(MRC[qb])}, {vr(d)}")
-        e(f"v_exp_f32 {vr(TMP + 2)}, -{vr(d)}")
-        e("s_nop 1")
-        e(f"v_mov_b32 {vr(TMP + 3)}, {vr(TMP + 2)}")
-        e(f"v_pk_mul_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(TMP + 2, 2)}")
+        c.append(f"v_max_f32 {vr(d)}, 0, {vr(MX[qb])}")
+        c.append(f"v_add_f32 {vr(MRC[qb])}, {vr(MRC[qb])}, {vr(d)}")
+        c.append(f"v_exp_f32 {vr(TMP + 2)}, -{vr(d)}")
+        c.append("s_nop 1")
+        c.append(f"v_mov_b32 {vr(TMP + 3)}, {vr(TMP + 2)}")
+        c.append(f"v_pk_mul_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(TMP + 2, 2)}")
         for base in range(A_O(qb, 0), A_O(qb, 0) + 64, 8):
             for i in range(8):
-                e(f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, {ar(base + i)}")
+                c.append(f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, {ar(base + i)}")
             for i in range(0, 8, 2):
-                e(f"v_pk_mul_f32 {vr(TMP + 4 + i, 2)}, {vr(TMP + 4 + i, 2)}, {vr(TMP + 2, 2)}")
+                c.append(f"v_pk_mul_f32 {vr(TMP + 4 + i, 2)}, {vr(TMP + 4 + i, 2)}, {vr(TMP + 2, 2)}")
             for i in range(8):
-                e(f"v_accvgpr_write_b32 {ar(base + i)}, {vr(TMP + 4 + i)}")
+                c.append(f"v_accvgpr_write_b32 {ar(base + i)}, {vr(TMP + 4 + i)}")
         for r in range(16):
-            e(f"v_sub_f32 {vr(S[sbuf] + 16 * qb + r)}, {vr(S[sbuf] + 16 * qb + r)}, {vr(d)}")
+            c.append(f"v_sub_f32 {vr(S[sbuf] + 16 * qb + r)}, {vr(S[sbuf] + 16 * qb + r)}, {vr(d)}")
         for r in range(16):
-            e(f"v_sub_f32 {vr(MINIT[qb] + r)}, {vr(MINIT[qb] + r)}, {vr(d)}")
-    e("s_nop 4")
-    e(f"{skip}:")
+            c.append(f"v_sub_f32 {vr(MINIT[qb] + r)}, {vr(MINIT[qb] + r)}, {vr(d)}")
+    c += ["s_nop 4", f"s_branch {back}"]
+    cold.extend(c)
 
 
 def exp_items(sbuf):
     """p = exp2(s c - m c) in place, then the bf16 P^T fragments"""
     it = []
     sreg = lambda qb, r: S[sbuf] + 16 * qb + r   # noqa: E731
-    if "nosoftmax" not in ABL:
+    if "nosoftmax" not in ABL and "noexp" not in ABL:
         for r in range(16):
             for qb in range(2):
                 it.append(("valu", f"v_exp_f32 {vr(sreg(qb, r))}, {vr(sreg(qb, r))}"))
@@ -249,10 +253,19 @@ def exp_items(sbuf):
 
 def sum_items(sbuf):
     """row sums of the p values left in S[sbuf] (done under the P.V MFMAs)"""
-    if "nosoftmax" in ABL:
+    if "nosoftmax" in ABL or "nosum" in ABL:
         return []
-    return [("valu", f"v_pk_add_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {vr(S[sbuf] + 16 * qb + r, 2)}")
-            for r in range(0, 16, 2) for qb in range(2)]
+    # pairwise tree in place (the p values are dead once converted): a chain of eight dependent
+    # v_pk_add_f32 per query block cost 7 cycles per instruction
+    it = []
+    sp = lambda qb, r: vr(S[sbuf] + 16 * qb + r, 2)   # noqa: E731
+    for step, starts in ((2, (0, 4, 8, 12)), (4, (0, 8)), (8, (0,))):
+        for r in starts:
+            for qb in range(2):
+                it.append(("valu", f"v_pk_add_f32 {sp(qb, r)}, {sp(qb, r)}, {sp(qb, r + step)}"))
+    for qb in range(2):
+        it.append(("valu", f"v_pk_add_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {sp(qb, 0)}"))
+    return it
 
 
 def mix(a, b):
@@ -274,11 +287,12 @@ def phase(mfmas, others):
     tags = phase.tags
     if "nomfma" in ABL:
         mfmas = []
-    if "nolds" in ABL:
-        for it in others:
-            if it[0] == "lds":
-                tags[it[2]] = -1
-        others = [it for it in others if it[0] != "lds"]
+    for flag, kinds in (("nolds", ("k", "vlo", "vhi")), ("novread", ("vlo", "vhi")), ("nokread", ("k",))):
+        if flag in ABL:
+            for it in others:
+                if it[0] == "lds" and it[2][0] in kinds:
+                    tags[it[2]] = -1
+            others = [it for it in others if not (it[0] == "lds" and it[2][0] in kinds)]
     n = max(1, len(mfmas))
     per = [len(others) * (i + 1) // n - len(others) * i // n for i in range(n)] if mfmas else []
     oi = 0
@@ -515,6 +529,11 @@ def main():
                 e(f"global_store_dwordx2 {vr(OP[qb], 2)}, {vr(S[1] + 2 * rg, 2)}, off offset:{db * 64 + rg * 16}")
             e("s_waitcnt vmcnt(0)")
         e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
+    end_l = ".Lr64_end%="
+    e(f"s_branch {end_l}")
+    for ln in cold:
+        e(ln)
+    e(f"{end_l}:")
     body_txt = "\n".join('    "' + ln.replace("\n\t", '\\n\\t') + '\\n"' for ln in out)
     clob_v = ", ".join(f'"v{i}"' for i in range(1, 256))
     clob_a = ", ".join(f'"a{i}"' for i in range(0, 256))
