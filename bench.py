@@ -110,10 +110,10 @@ def roofline_leg(shape, dev, frames, nfpb, fs):
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same shapes
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f)["attention_w8_kernel<0>"]["hbm_bytes_per_launch"]
+            traffic = json.load(f)["attention_r64_kernel"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    att = {"bound": "mfma", "kernel": "attention_w8_kernel<0> (self-attention over the KV cache)",
+    att = {"bound": "mfma", "kernel": "attention_r64_kernel (self-attention over the KV cache)",
            "achieved": avg_flops / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the same 7 cache lengths)",
