@@ -46,8 +46,40 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// Epilogue shared by both structures: the lane holds out[m][n .. n+3] for each (mt, nt) of its
-// wave's 64 x 64 sub-tile; m = mrow + 16 mt, n = ncol + 16 nt.
+// Epilogue arithmetic on the 4 consecutive output columns a lane owns of row m: bias, GELU, gate, residual.
+template <int EPI>
+__device__ __forceinline__ bf16x4 epi_apply(const GemmP& p, const f32x4& a4, int m, int n, const bf16_t* e0row) {
+  float y[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[j] = a4[j];
+  if (p.bias) {
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] += (float)b[j];
+  }
+  if (EPI == SF_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+  }
+  if (EPI == SF_EPI_BIAS_GATE_RESID) {
+    const bf16x4 gm = *reinterpret_cast<const bf16x4*>(p.gate_mod + n);
+    const bf16x4 ge = *reinterpret_cast<const bf16x4*>(e0row + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] *= (float)(bf16_t)((float)gm[j] + (float)ge[j]);
+  }
+  if (EPI == SF_EPI_BIAS_RESID || EPI == SF_EPI_BIAS_GATE_RESID) {
+    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
+  return o;
+}
+
+// Direct epilogue: the lane holds out[m][n .. n+3] for each (mt, nt) of its wave's sub-tile
+// (m = mrow + 16 mt, n = ncol + 16 nt) and stores them as they are (8-byte pieces).
 template <int EPI, int MT>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int mrow, int ncol) {
 #pragma unroll
@@ -64,34 +96,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = acc[mt][nt];
         continue;
       }
-      float y[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j];
-      if (p.bias) {
-        const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] += (float)b[j];
-      }
-      if (EPI == SF_EPI_BIAS_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
-      }
-      if (EPI == SF_EPI_BIAS_GATE_RESID) {
-        const bf16x4 gm = *reinterpret_cast<const bf16x4*>(p.gate_mod + n);
-        const bf16x4 ge = *reinterpret_cast<const bf16x4*>(e0row + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] *= (float)(bf16_t)((float)gm[j] + (float)ge[j]);
-      }
-      if (EPI == SF_EPI_BIAS_RESID || EPI == SF_EPI_BIAS_GATE_RESID) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
-      *reinterpret_cast<bf16x4*>(p.out + (long)m * p.ldo + n) = o;
+      *reinterpret_cast<bf16x4*>(p.out + (long)m * p.ldo + n) = epi_apply<EPI>(p, acc[mt][nt], m, n, e0row);
     }
+  }
+}
+
+// Epilogue through LDS: the wave's (16 MT) x 64 sub-tile is written to its own LDS region as bf16 rows of
+// 128 B (16-byte chunk c of row r at c ^ (r & 7): 2-way conflicts at most on the 8-byte writes, none on the
+// reads) and read back row-wise, so that every global store instruction covers 8 whole 128-byte rows.
+// The direct form writes 32-byte pieces of 16 different rows per instruction: for the 84 MB ffn.0 output
+// that is a quarter of HBM's write efficiency and cost 12-20 us per 256 x 256 tile.
+template <int EPI, int MT>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x4 (&acc)[MT][4], int m_base, int n_base, char* wbuf, int lane) {
+  const int r16 = lane & 15, cg = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = mt * 16 + r16;
+    const int m = min(m_base + row, p.M - 1);
+    const bf16_t* e0row = nullptr;
+    if (EPI == SF_EPI_BIAS_GATE_RESID) e0row = p.gate_e0 + (long)(m / p.rows_per_group) * p.gate_group_stride;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = nt * 16 + cg * 4;                       // 0..63 within the wave's columns
+      const int n = min(n_base + col, p.N - 4);
+      const bf16x4 o = epi_apply<EPI>(p, acc[mt][nt], m, n, e0row);
+      const int chunk = (col >> 3) ^ (row & 7);
+      *reinterpret_cast<bf16x4*>(wbuf + row * 128 + (chunk << 4) + (col & 4) * 2) = o;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes (the region is private to the wave)
+  const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 2 * MT; ++i) {
+    const int row = i * 8 + rr;
+    const int m = m_base + row, n = n_base + ch * 8;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(wbuf + row * 128 + ((ch ^ (row & 7)) << 4));
+    if (m < p.M && n < p.N) *reinterpret_cast<bf16x8*>(p.out + (long)m * p.ldo + n) = v;
   }
 }
 
@@ -203,7 +243,126 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
   // ---- epilogue: lane holds out[m][n .. n+3] for (mt, nt)
   const int mrow = m0 + wr * 64 + (lane & 15);
   const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
-  gemm_epilogue<EPI, 4>(p, acc, mrow, ncol);
+  if (EPI != SF_EPI_F32 && (p.N & 7) == 0 && (p.ldo & 7) == 0)   // (the k-loop's last __syncthreads has released the stages)
+    gemm_epilogue_lds<EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, smem + wave * 8192, lane);
+  else
+    gemm_epilogue<EPI, 4>(p, acc, mrow, ncol);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Large-tile structure for wide GEMMs (ffn.0): 256 x 256 output tile per 512-thread workgroup, 8 waves as
+// 2 x 4, 128 x 64 per wave (8 x 4 MFMA tiles), ONE workgroup per CU (two waves per SIMD), two 64 KiB
+// stages.  Per kflop it moves 31 B through LDS instead of 47 (fragment reads 23 + tile writes 8), the
+// measured limiter of the 128 x 128 kernel (tools/probes/gemm_probe.hip: 1481 vs 1050 TFLOP/s for the bare
+// loops).  Only worth it when the tile count fills the 256 CUs in nearly whole rounds.
+constexpr int BBM = 256, BBN = 256;
+constexpr int BIG_THREADS = 512;
+constexpr int BIG_TILE_BYTES = BBM * BK * 2;      // 32 KiB per operand tile
+constexpr int BIG_STAGE = 2 * BIG_TILE_BYTES;
+constexpr int BIG_LDS = 2 * BIG_STAGE;            // 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GROUP_M = 4;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = wg / width, first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * width;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int m0 = tm * BBM, n0 = tn * BBN;
+
+  // staging: wave w issues pieces 4w .. 4w+3 (8 rows x 128 B each) of the A tile and of the W tile
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    a_src[i] = p.a + (long)min(m0 + r, p.M - 1) * p.lda + c * 8;
+    w_src[i] = p.w + (long)min(n0 + r, p.N - 1) * p.ldw + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * BIG_STAGE + wave * 4096;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + k0, base + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(w_src[i] + k0, base + BIG_TILE_BYTES + i * 1024);
+  };
+
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int swz = (i16 >> 1) & 7;
+  const int x_row_off = (wr * 128 + i16) * 128;
+  const int w_row_off = BIG_TILE_BYTES + (wc * 64 + i16) * 128;
+  const int coff[2] = {((0 + kq) ^ swz) << 4, ((4 + kq) ^ swz) << 4};
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* buf = smem + cur * BIG_STAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 xf[8], wf[4];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff[s2]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff[s2]);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int mrow = m0 + wr * 128 + (lane & 15);
+  const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
+#ifdef SF_ABL_NOEPI   // timing-only: one store per thread keeps the accumulators alive
+  float sacc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (mrow < p.M && ncol < p.N) p.out[(long)mrow * p.ldo + ncol] = (bf16_t)sacc;
+#else
+  if ((p.N & 7) == 0 && (p.ldo & 7) == 0)   // (the trailing __syncthreads of the k-loop has released the stages)
+    gemm_epilogue_lds<EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, smem + wave * 16384, lane);
+  else
+    gemm_epilogue<EPI, 8>(p, acc, mrow, ncol);
+#endif
+}
+
+template <int EPI>
+int launch_big(GemmP& p, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    attr = true;
+  }
+  p.tiles_m = (p.M + BBM - 1) / BBM;
+  p.tiles_n = (p.N + BBN - 1) / BBN;
+  hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(BIG_THREADS), BIG_LDS, s, p);
+  return 0;
 }
 
 
@@ -234,6 +393,26 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
   p.tiles_n = (a->N + BN - 1) / BN;
   hipStream_t s = (hipStream_t)stream;
   p.tiles_m = (a->M + BM - 1) / BM;
+  // wide outputs whose 256 x 256 tiles fill the chip in nearly whole rounds take the large-tile structure
+  // (env SF_GEMM_BIG=1/0 forces / forbids it: A/B timing and tests only)
+  {
+    const long tb = (long)((a->M + BBM - 1) / BBM) * ((a->N + BBN - 1) / BBN);
+    const long rounds = (tb + 255) / 256;
+    const char* env = getenv("SF_GEMM_BIG");
+    bool big = a->N >= 2048 && a->M >= 1024 && tb >= 512 && (double)tb / (rounds * 256) >= 0.8;
+    if (env) big = env[0] == '1';
+    if (big && a->epilogue != SF_EPI_F32) {
+      switch (a->epilogue) {
+        case SF_EPI_BIAS: launch_big<SF_EPI_BIAS>(p, s); break;
+        case SF_EPI_BIAS_GELU: launch_big<SF_EPI_BIAS_GELU>(p, s); break;
+        case SF_EPI_BIAS_RESID: launch_big<SF_EPI_BIAS_RESID>(p, s); break;
+        case SF_EPI_BIAS_GATE_RESID: launch_big<SF_EPI_BIAS_GATE_RESID>(p, s); break;
+        default: SF_CHECK(false, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
+      }
+      SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
+      return 0;
+    }
+  }
   const dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
   switch (a->epilogue) {
     case SF_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS>, grid, block, GEMM_LDS, s, p); break;

@@ -110,6 +110,28 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm(a.float(), w)  # wrong dtype
 
 
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_resid"])
+def test_gemm_large_tile_structure(epi):
+    """Wide outputs whose 256 x 256 tiles fill the chip dispatch the 8-wave large-tile kernel (ffn.0's shape);
+    ragged M (4680 = 18 x 256 + 72) exercises its row clamping."""
+    M, N, K = 4680, 8960, 192
+    g = torch.Generator().manual_seed(77)
+    a, w, bias = bf((M, K), g), bf((N, K), g, 1.0 / K ** 0.5), bf((N,), g, 0.5)
+    y = a.float() @ w.float().t() + bias.float()
+    kw = {}
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(y, approximate="tanh")
+    elif epi == "gate_resid":
+        resid, gate_mod, e0 = bf((M, N), g), bf((N,), g, 0.5), bf((3, 6, N), g, 0.5)
+        gate = (gate_mod.float()[None] + e0[:, 2].float()).to(torch.bfloat16).float()
+        ref = resid.float() + y * gate.repeat_interleave(M // 3, dim=0)
+        kw = dict(resid=resid.to(DEV), gate_mod=gate_mod.to(DEV), gate_e0=e0[:, 2].to(DEV), rows_per_group=M // 3)
+    else:
+        ref = y
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), epilogue=epi, **kw)
+    assert rel(out, ref) < 4e-3
+
+
 # ----------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 32, 64), (1, 2, 100, 200), (2, 3, 130, 24), (1, 4, 24, 512),
                                         (1, 2, 1560, 4680), (1, 1, 200, 1561)])
