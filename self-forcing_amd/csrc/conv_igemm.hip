@@ -190,6 +190,51 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
   // ---- epilogue: the lane holds out[m][n .. n+3] for (mt, nt); m = mrow + 16 mt, n = ncol + 16 nt
   const int mrow = m0 + wr * 64 + (lane & 15);
   const int ncol = n0 + wc * (16 * NT) + (lane >> 4) * 4;
+  if (EPI != SF_CONV_BIAS_CLAMP_F32 && p.inter_c == 0 && (p.Cout & 7) == 0 && (p.ldo & 7) == 0) {
+    // Through LDS: the 128 x BN tile is assembled as bf16 rows (padded by 16 B against bank conflicts) and
+    // written back in 16-byte pieces along the rows -- with all channels in one tile that is one contiguous
+    // region of the output volume.  The direct form stores 8-byte pieces of 16 different positions per
+    // instruction (32-byte partial lines): a quarter of HBM's write efficiency on the 300 MB volumes.
+    constexpr int RBP = 64 * NT + 16;    // padded row bytes
+    char* obuf = smem;                   // (the k-loop's last __syncthreads has released the stages)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = wr * 64 + mt * 16 + (lane & 15);
+      const int m = min(m0 + row, p.M - 1);
+      const long grow = (long)p.out_frame0 * p.HW + m;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = wc * (16 * NT) + nt * 16 + (lane >> 4) * 4;
+        const int n = min(n0 + col, p.Cout - 4);
+        float y[4];
+        const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j] + (float)b[j];
+        if (EPI == SF_CONV_BIAS_RESID) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + grow * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
+        *reinterpret_cast<bf16x4*>(obuf + row * RBP + col * 2) = o;
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = 4 * NT;          // 16-byte chunks per row
+#pragma unroll
+    for (int i = 0; i < (CBM * CPR) / CONV_THREADS; ++i) {
+      const int id = i * CONV_THREADS + tid;
+      const int row = id / CPR, ch = id - row * CPR;
+      const int m = m0 + row, n = n0 + ch * 8;
+      if (m < p.M && n < p.Cout) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(obuf + row * RBP + ch * 16);
+        *reinterpret_cast<bf16x8*>(p.out + ((long)p.out_frame0 * p.HW + m) * p.ldo + n) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = mrow + mt * 16;
