@@ -324,6 +324,14 @@ def main():
                             "worst_chunk_fps": 4 * nfpb / max(steady), "realtime_playback_fps": 16,
                             "pixels_decoded": not a.no_vae,
                             "note": "one rollout alone on the GPU, each chunk denoised then decoded to pixels before it is yielded"}
+        if not a.no_vae:   # decode of chunk k on a second HIP stream under the denoising of chunk k+1
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
+            n_chunks = sum(1 for _ in pipe0.stream(noise, [prompts[0]], overlap_decode=True))
+            torch.cuda.synchronize()
+            out["streaming"]["overlapped_decode_clip_fps"] = decoded / (time.perf_counter() - t_start)
+            out["streaming"]["serial_decode_clip_fps"] = decoded / sum(ts)
+            assert n_chunks == len(ts)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(shape, sd, 1, nfpb, len(step_list), a.frames)
     if dist is not None:

@@ -213,12 +213,17 @@ class CausalInferencePipeline(torch.nn.Module):
                 on_chunk_end()
             current_start_frame += current_num_frames
 
-    def stream(self, noise: torch.Tensor, text_prompts: List[str], skip_last_context: bool = True):
+    def stream(self, noise: torch.Tensor, text_prompts: List[str], skip_last_context: bool = True,
+               overlap_decode: bool = False):
         """Chunk-at-a-time generation (the streaming boundary; mirrors the inline loop of the
-        reference's demo.py:303-468): yields `(chunk_index, latents [B, f, C, H, W], pixels)` per chunk
-        as soon as it is denoised, so a consumer can decode / send chunk k while chunk k+1 is being
-        generated.  `pixels` comes from `vae.decode_chunk(latents, chunk_index)` when the injected VAE
-        has a streaming decoder, else from `decode_to_pixel` on the chunk alone."""
+        reference's demo.py:303-468): yields `(chunk_index, latents [B, f, C, H, W], pixels)` per chunk.
+        `pixels` comes from `vae.decode_chunk(latents, chunk_index)` when the injected VAE has a streaming
+        decoder, else from `decode_to_pixel` on the chunk alone.
+
+        overlap_decode=False: chunk k is decoded right after it is denoised and yielded at once (lowest
+        latency to the first frame).  overlap_decode=True: the decode of chunk k runs on a second HIP stream
+        while chunk k+1 is being denoised (it fills the CUs the denoiser's single-round kernels leave idle);
+        chunk k is then yielded one chunk later, as soon as its decode has finished."""
         batch_size, num_frames, num_channels, height, width = noise.shape
         if self.independent_first_frame:
             assert (num_frames - 1) % self.num_frame_per_block == 0
@@ -238,9 +243,37 @@ class CausalInferencePipeline(torch.nn.Module):
                 self.crossattn_cache[block_index]["is_init"] = False
             self._reset_kv_indices()
         decode_chunk = getattr(self.vae, "decode_chunk", None)
-        for chunk_idx, start_frame, x0 in self._denoise_chunks(noise, conditional_dict, all_num_frames, 0, 0, skip_last_context):
+
+        def decode(x0, chunk_idx):
             pixels = decode_chunk(x0, chunk_idx) if decode_chunk is not None else self.vae.decode_to_pixel(x0, use_cache=False)
-            yield chunk_idx, x0, (pixels * 0.5 + 0.5).clamp(0, 1)
+            return (pixels * 0.5 + 0.5).clamp(0, 1)
+
+        chunks = self._denoise_chunks(noise, conditional_dict, all_num_frames, 0, 0, skip_last_context)
+        if not overlap_decode:
+            for chunk_idx, start_frame, x0 in chunks:
+                yield chunk_idx, x0, decode(x0, chunk_idx)
+            return
+        if getattr(self, "_decode_stream", None) is None:
+            self._decode_stream = torch.cuda.Stream(device=noise.device)
+        side, main = self._decode_stream, torch.cuda.current_stream(noise.device)
+        pending = None            # (chunk_idx, x0, pixels, done event) of the chunk being decoded on the side stream
+        for chunk_idx, start_frame, x0 in chunks:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                x0.record_stream(side)
+                pixels = decode(x0, chunk_idx)
+                done = torch.cuda.Event()
+                done.record(side)
+            if pending is not None:
+                pending[3].synchronize()
+                yield pending[:3]
+            pending = (chunk_idx, x0, pixels, done)
+        if pending is not None:
+            pending[3].synchronize()
+            main.wait_event(pending[3])
+            yield pending[:3]
 
     # ------------------------------------------------------------------------------------------
     def _cache_tokens(self, total_frames: Optional[int] = None) -> int:

@@ -269,6 +269,27 @@ def test_streaming_matches_batch_inference(sd_reduced):
     assert int(pipe.kv_cache1[0]["global_end_index"]) == 6 * FS
 
 
+def test_streaming_overlapped_decode_matches_serial(sd_reduced):
+    """stream(overlap_decode=True): the VAE decode of chunk k runs on a second HIP stream under the denoising
+    of chunk k+1 and is yielded one chunk later -- same latents, same pixels, bit for bit."""
+    from self_forcing_amd import vae_weights as vw
+    g = torch.Generator().manual_seed(41)
+    noise = torch.randn(1, 6, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    eps = [torch.randn(2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(9)]
+    pipe = make_pipe(sd_reduced, 2, False, 5.0, pe=pe)
+    pipe.vae = sfa.WanVAEWrapper(vw.synth_vae_state_dict(vw.VAE_REDUCED, seed=0), device=DEV, shape=vw.VAE_REDUCED)
+    q = list(eps)
+    pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+    serial = [(i, x.clone(), p.clone()) for i, x, p in pipe.stream(noise, ["p"])]
+    q.extend(eps)
+    over = [(i, x.clone(), p.clone()) for i, x, p in pipe.stream(noise, ["p"], overlap_decode=True)]
+    assert [c[0] for c in over] == [0, 1, 2]
+    assert serial[0][2].shape == (1, 5, 3, 8 * LAT_H, 8 * LAT_W) and serial[1][2].shape[1] == 8
+    for a, b in zip(serial, over):
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 def test_add_condition_pose_tokens_vs_oracle():
     """x += pose_proj(add_condition) after the patch embedding (the intent of causal_model.py:786-819).
     Parity for this branch is pinned by the oracle restatement only: the reference's own inference
