@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 2
+#define SF_HIP_ABI_VERSION 3
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -317,6 +317,56 @@ int sf_vae_reset(const sf_vae_model* model, void* state, size_t state_bytes, int
 int sf_vae_decode_frame(const sf_vae_model* model, void* state, size_t state_bytes, void* scratch,
                         size_t scratch_bytes, const void* latent_frame, int lat_h, int lat_w,
                         int first_chunk, float* pixels_out, void* stream);
+
+/* ==========================================================================================
+ * umT5 text encoder (prompt token ids -> prompt embeddings): WanTextEncoder.forward after its tokenizer
+ * (utils/wan_wrapper.py:40-55) -> T5Encoder.forward (wan/modules/t5.py:299-312).  Runs once per prompt.
+ * ========================================================================================== */
+
+/* nn.Embedding lookup: out[t][:] = table[ids[t]][:] (ids int64; an id outside [0, vocab) is an error
+ * reported by the caller -- the kernel clamps). */
+int sf_embedding_gather(const int64_t* ids, const void* table, void* out, int n_tokens, int dim, int vocab,
+                        void* stream);
+
+/* Logits -> probabilities of T5Attention (t5.py:104-118) for all heads of one sample:
+ *   p[h][i][j] = softmax_j( s[h][i][j] + emb[rel_bucket[j - i + L - 1]][h] + (key_mask[j] ? 0 : -inf) ),  j < L
+ *   p[h][i][j] = 0 for L <= j < ld  (zero padding so that p can be the A operand of a K = ld GEMM)
+ * s float32 [H][L][ld], p bf16 [H][L][ld], emb bf16 [num_buckets][H] (T5RelativeEmbedding.embedding.weight),
+ * rel_bucket int32 [2L-1] (host-computed bucket of every relative position, t5.py:236-256), key_mask int64 [L]. */
+int sf_t5_softmax_bias(const float* s, void* p, const void* emb, const int32_t* rel_bucket, const int64_t* key_mask,
+                       int H, int L, int ld, void* stream);
+
+/* out[i] = a[i] * b[i] (bf16; the gated-GELU product fc1(x) * gelu(gate(x)), t5.py:138); in place allowed. */
+int sf_mul_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
+/* rows of x [B*L][dim] whose mask entry is 0 are set to zero (WanTextEncoder.forward, wan_wrapper.py:50-51). */
+int sf_zero_masked_rows(void* x, const int64_t* mask, int rows, int dim, void* stream);
+
+typedef struct sf_t5_layer {       /* T5SelfAttention, t5.py:146-178 */
+  const void* norm1_w;             /* [dim] */
+  const void* qk_w;                /* attn.q | attn.k stacked: [2*dim_attn][dim] */
+  const void* v_w;                 /* [dim_attn][dim] */
+  const void* o_w;                 /* [dim][dim_attn] */
+  const void* norm2_w;
+  const void* gate_w;              /* ffn.gate.0: [dim_ffn][dim] */
+  const void* fc1_w;               /* [dim_ffn][dim] */
+  const void* fc2_w;               /* [dim][dim_ffn] */
+  const void* pos_emb;             /* pos_embedding.embedding.weight [num_buckets][num_heads] */
+} sf_t5_layer;
+
+typedef struct sf_t5_model {
+  int32_t vocab, dim, dim_attn, dim_ffn, num_heads, num_layers, num_buckets;
+  float eps;
+  const void* token_embedding;     /* [vocab][dim] */
+  const sf_t5_layer* layers_host;  /* HOST array [num_layers] */
+  const void* final_norm_w;        /* [dim] */
+} sf_t5_model;
+
+size_t sf_t5_workspace_bytes(const sf_t5_model* model, int batch, int seq_len);
+/* ids, mask: int64 [batch][seq_len] (mask 1 = token, a prefix mask); rel_bucket int32 [2 seq_len - 1];
+ * out bf16 [batch][seq_len][dim], rows past each prompt's length zero. */
+int sf_t5_encode(const sf_t5_model* model, const int64_t* ids, const int64_t* mask, const int32_t* rel_bucket,
+                 int batch, int seq_len, void* out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # epilogue codes (enum sf_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
@@ -106,6 +106,16 @@ class VaeModel(C.Structure):
     ]
 
 
+class T5Layer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("norm1_w", "qk_w", "v_w", "o_w", "norm2_w", "gate_w", "fc1_w", "fc2_w", "pos_emb")]
+
+
+class T5Model(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("vocab", "dim", "dim_attn", "dim_ffn", "num_heads", "num_layers", "num_buckets")]
+                + [("eps", C.c_float), ("token_embedding", C.c_void_p), ("layers_host", C.POINTER(T5Layer)),
+                   ("final_norm_w", C.c_void_p)])
+
+
 # name -> (restype, argtypes); every symbol include/sf_hip.h declares
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -135,6 +145,12 @@ SIGNATURES = {
     "sf_vae_scratch_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i]),
     "sf_vae_reset": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _i, _i, _vp]),
     "sf_vae_decode_frame": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _vp, _sz, _vp, _i, _i, _i, _vp, _vp]),
+    "sf_embedding_gather": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sf_t5_softmax_bias": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sf_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "sf_zero_masked_rows": (C.c_int, [_vp, _vp, _i, _i, _vp]),
+    "sf_t5_workspace_bytes": (C.c_size_t, [C.POINTER(T5Model), _i, _i]),
+    "sf_t5_encode": (C.c_int, [C.POINTER(T5Model), _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None
