@@ -58,6 +58,9 @@ typedef struct sf_gemm_args {
   int32_t M, N, K;
   int32_t lda, ldw, ldo, ldr;
   int32_t epilogue;    /* enum sf_epilogue */
+  int32_t batch;       /* > 1: `batch` independent products; entry b uses a + b*a_bstride, w + b*w_bstride,
+                          out + b*o_bstride, resid + b*r_bstride (elements; bias / gates shared); 0 or 1: one product */
+  int64_t a_bstride, w_bstride, o_bstride, r_bstride;
 } sf_gemm_args;
 
 int sf_gemm_bf16(const sf_gemm_args* args, void* stream);

