@@ -252,19 +252,20 @@ def exp_items(sbuf):
 
 
 def sum_items(sbuf):
-    """row sums of the p values left in S[sbuf] (done under the P.V MFMAs)"""
+    """row sums of the p values left in S[sbuf] (done under the P.V MFMAs).  Plain v_add_f32, pairwise tree in
+    place (the p values are dead once converted): packed fp32 instructions (v_pk_add_f32) do NOT execute
+    beside MFMAs -- 48 of them between 8 MFMAs cost 139 ns on top of the MFMAs' 130 ns, 48 v_add_f32 cost 3 ns
+    (tools/probes/overlap_probe.hip) -- so the 16 packed adds of the first version cost 65 us per launch."""
     if "nosoftmax" in ABL or "nosum" in ABL:
         return []
-    # pairwise tree in place (the p values are dead once converted): a chain of eight dependent
-    # v_pk_add_f32 per query block cost 7 cycles per instruction
     it = []
-    sp = lambda qb, r: vr(S[sbuf] + 16 * qb + r, 2)   # noqa: E731
-    for step, starts in ((2, (0, 4, 8, 12)), (4, (0, 8)), (8, (0,))):
-        for r in starts:
+    sr = lambda qb, r: vr(S[sbuf] + 16 * qb + r)   # noqa: E731
+    for step in (1, 2, 4, 8):
+        for r in range(0, 16, 2 * step):
             for qb in range(2):
-                it.append(("valu", f"v_pk_add_f32 {sp(qb, r)}, {sp(qb, r)}, {sp(qb, r + step)}"))
+                it.append(("valu", f"v_add_f32 {sr(qb, r)}, {sr(qb, r)}, {sr(qb, r + step)}"))
     for qb in range(2):
-        it.append(("valu", f"v_pk_add_f32 {vr(L2[qb], 2)}, {vr(L2[qb], 2)}, {sp(qb, 0)}"))
+        it.append(("valu", f"v_add_f32 {vr(L2[qb])}, {vr(L2[qb])}, {sr(qb, 0)}"))
     return it
 
 

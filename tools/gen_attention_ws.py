@@ -252,9 +252,12 @@ def a_exp_items(sbuf):
         for r in range(16):
             for qb in range(2):
                 it.append(("valu", f"v_exp_f32 {vr(sreg(qb, r))}, {vr(sreg(qb, r))}"))
+        # row sums with plain v_add_f32 (packed fp32 instructions do not execute beside MFMAs); the p values must
+        # survive for the convert, so two running sums per block instead of an in-place tree
         for r in range(0, 16, 2):
             for qb in range(2):
-                it.append(("valu", f"v_pk_add_f32 {vr(A_L2[qb], 2)}, {vr(A_L2[qb], 2)}, {vr(sreg(qb, r), 2)}"))
+                it.append(("valu", f"v_add_f32 {vr(A_L2[qb])}, {vr(A_L2[qb])}, {vr(sreg(qb, r))}"))
+                it.append(("valu", f"v_add_f32 {vr(A_L2[qb] + 1)}, {vr(A_L2[qb] + 1)}, {vr(sreg(qb, r + 1))}"))
     for r in range(0, 16, 2):
         for qb in range(2):
             it.append(("valu", f"v_cvt_pk_bf16_f32 {vr(sreg(qb, r >> 1))}, {vr(sreg(qb, r))}, {vr(sreg(qb, r + 1))}"))
