@@ -514,15 +514,18 @@ def b_step(kind):
     if kind != "final":
         clamp_tile(SOFFK, 2)
         clamp_tile(SOFFV, 0)
-        dmas = b_dma_items(K_SRD, SOFFK, KS_DMA) + b_dma_items(V_SRD, SOFFV, VS_DMA)
+        dmas = b_dma_items(V_SRD, SOFFV, VS_DMA) + b_dma_items(K_SRD, SOFFK, KS_DMA)
     if kind == "first":
         for _, t in dmas:
             e(t)
     else:
         # tile t-1 (V slot / P parity / hand-off parity are where the address registers point)
-        phase([], mix(b_p_reads(0) + b_v_reads(0, 0), dmas[:4]))
+        # LDS-DMA requests between the MFMAs of the first unit, one per two MFMAs (tools/probes/dma_probe.hip: a
+        # burst of 8 blocks the wave for ~220 ns, the same 8 between 16 MFMAs cost ~20 ns); the second unit's
+        # MFMAs are the time they have to land before the next barrier
+        phase([], b_p_reads(0) + b_v_reads(0, 0))
         b_rescale_check(0)
-        phase(b_pv_mfmas(0), mix(b_p_reads(1) + b_v_reads(1, 1), dmas[4:]))
+        phase(b_pv_mfmas(0), mix(dmas, b_p_reads(1) + b_v_reads(1, 1)))
         b_rescale_check(1)
         phase(b_pv_mfmas(1), [])
     if kind != "final":
