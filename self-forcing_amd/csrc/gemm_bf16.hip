@@ -211,39 +211,41 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* buf = smem + cur * STAGE_BYTES;
-    // fragments of both 32-deep sub-steps: the second set is requested while the first set's MFMAs
-    // run (issue order pinned below; left alone, hipcc reads just in time and every group of MFMAs
-    // waits out an LDS round trip)
+    // The k-step as eight pinned slices of {2 MFMAs of the first 32-deep sub-step, one fragment read of the
+    // second sub-step, ONE LDS-DMA request of the next tile}, then the second sub-step's 16 MFMAs.  Left to the
+    // scheduler the 8 requests go out as a burst, which blocks the wave for ~220 ns per k-step (the TCP->LDS
+    // path moves 64 B/clk/CU); one request per two MFMAs costs ~20 ns (tools/probes/dma_probe.hip).  The last
+    // k-step re-requests its own tile into the idle buffer so that the loop body stays branch-free.
+    const int kn = min(kt + 1, nk - 1) * BK;
+    char* sbase = smem + (cur ^ 1) * STAGE_BYTES + wave * 4096;
     bf16x8 xf0[4], wf0[4], xf1[4], wf1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff0);
       wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff0);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      xf1[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff1);
-      wf1[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff1);
+    for (int i = 0; i < 8; ++i) {
+      const int mt = i >> 1, nt0 = (i & 1) * 2;
+      acc[mt][nt0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt0], xf0[mt], acc[mt][nt0], 0, 0, 0);
+      acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt0 + 1], xf0[mt], acc[mt][nt0 + 1], 0, 0, 0);
+      if (i < 4) {
+        xf1[i] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + i * 2048 + coff1);
+        glds16(a_src[i] + kn, sbase + i * 1024);
+      } else {
+        wf1[i - 4] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + (i - 4) * 2048 + coff1);
+        glds16(w_src[i - 4] + kn, sbase + TILE_BYTES + (i - 4) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_barrier(0);   // keep the wait + barrier BEHIND the MFMAs: the requests need the time to land
     __syncthreads();  // drains the in-flight LDS-DMA (vmcnt(0)) and orders the buffer swap
   }
 
@@ -325,21 +327,37 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     const char* buf = smem + cur * BIG_STAGE;
+    // eight pinned slices of {4 MFMAs of the first sub-step, fragment reads of the second, ONE LDS-DMA request of
+    // the next tile} (see gemm_bf16_kernel), then the second sub-step's 32 MFMAs
+    const int kn = min(kt + 1, nk - 1) * BK;
+    char* sbase = smem + (cur ^ 1) * BIG_STAGE + wave * 4096;
+    bf16x8 xf0[8], wf0[4], xf1[8], wf1[4];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 xf[8], wf[4];
+    for (int t = 0; t < 8; ++t) xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff[0]);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff[s2]);
+    for (int t = 0; t < 4; ++t) wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff[s2]);
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < 4; ++nt)
+        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[i], acc[i][nt], 0, 0, 0);
+      xf1[i] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + i * 2048 + coff[1]);
+      if (i < 4) {
+        wf1[i] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + i * 2048 + coff[1]);
+        glds16(a_src[i] + kn, sbase + i * 1024);
+      } else {
+        glds16(w_src[i - 4] + kn, sbase + BIG_TILE_BYTES + (i - 4) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
   const int mrow = m0 + wr * 128 + (lane & 15);

@@ -527,6 +527,8 @@ def main():
             for i in range(8):
                 e(f"v_cvt_pk_bf16_f32 {vr(S[1] + i)}, {vr(S[0] + 2 * i)}, {vr(S[0] + 2 * i + 1)}")
             for rg in range(4):
+                if "nostore" in ABL and (db or rg):
+                    continue
                 e(f"global_store_dwordx2 {vr(OP[qb], 2)}, {vr(S[1] + 2 * rg, 2)}, off offset:{db * 64 + rg * 16}")
             e("s_waitcnt vmcnt(0)")
         e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
