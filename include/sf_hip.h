@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 3
+#define SF_HIP_ABI_VERSION 4
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -139,6 +139,16 @@ int sf_unpatchify_x0(const void* head_out, const void* xt, const void* timestep,
 int sf_add_noise(const void* x0, const void* eps, const void* timestep, int t_is_int64,
                  const float* sigmas, const float* timesteps, int n_table, void* out, int n_outer,
                  int64_t inner, void* stream);
+
+/* out[i] = sum_{k < n_terms} coefs[k] * xs[k][i]   (bf16 tensors of n elements, fp32 accumulation in the order
+ * k = 0, 1, ...; one rounding to bf16 at the end; 1 <= n_terms <= SF_LINCOMB_MAX; `out` may alias any input).
+ * `xs` and `coefs` are HOST arrays (device pointers / scalars), read before the call returns.
+ * Replaces the tensor arithmetic of the 50-step sampler: the classifier-free-guidance blend
+ * (pipeline/causal_diffusion_inference.py:423-424) and FlowUniPCMultistepScheduler's convert_model_output /
+ * multistep_uni_p_bh_update / multistep_uni_c_bh_update (wan/utils/fm_solvers_unipc.py:279-347, :350-484, :486-626),
+ * all of which are linear in their tensors with scalar coefficients the host evaluates. */
+#define SF_LINCOMB_MAX 6
+int sf_lincomb_bf16(void* out, const void* const* xs, const float* coefs, int n_terms, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * One whole denoiser pass: CausalWanModel._forward_inference + flow->x0

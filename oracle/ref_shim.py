@@ -112,3 +112,68 @@ def build_wrapper(ns, model, shift: float):
     w.seq_len = 32760
     w.post_init()
     return w
+
+
+def load_sampler():
+    """Additionally import the 50-step classifier-free-guidance sampler: `wan/utils/fm_solvers_unipc.py` and
+    `pipeline/causal_diffusion_inference.py`.
+
+    Both inherit from diffusers' `SchedulerMixin` / `ConfigMixin`, which is not installed here.  The stand-ins below
+    carry NO numerical content: `register_to_config` records the constructor's keyword arguments (with defaults) as
+    `self.config.<name>`, which is all the scheduler reads from the mixins; `deprecate` is a no-op; the scheduler's
+    arithmetic comes entirely from the reference's own file.  `wan.modules.clip` (needs torchvision) is replaced by
+    a placeholder because the pipeline only instantiates it when no image encoder is injected."""
+    ns = load()
+    if hasattr(ns, "CausalDiffusionInferencePipeline"):
+        return ns
+    import dataclasses
+    import enum
+    import functools
+    import inspect
+    import torch
+
+    def register_to_config(init):
+        @functools.wraps(init)
+        def inner(self, *args, **kwargs):
+            bound = inspect.signature(init).bind(self, *args, **kwargs)
+            bound.apply_defaults()
+            self.config = types.SimpleNamespace(**{k: v for k, v in bound.arguments.items() if k != "self"})
+            init(self, *args, **kwargs)
+        return inner
+
+    class ConfigMixin:
+        def register_to_config(self, **kw):
+            self.config.__dict__.update(kw)
+
+    class SchedulerMixin:
+        pass
+
+    @dataclasses.dataclass
+    class SchedulerOutput:
+        prev_sample: torch.Tensor
+
+    class KarrasDiffusionSchedulers(enum.Enum):
+        UniPCMultistepScheduler = 1
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    mod("diffusers.schedulers")
+    mod("diffusers.schedulers.scheduling_utils", KarrasDiffusionSchedulers=KarrasDiffusionSchedulers,
+        SchedulerMixin=SchedulerMixin, SchedulerOutput=SchedulerOutput)
+    mod("diffusers.utils", deprecate=lambda *a, **k: None, is_scipy_available=lambda: False)
+    mod("diffusers.utils.torch_utils", randn_tensor=lambda shape, generator=None, device=None, dtype=None:
+        torch.randn(shape, generator=generator, device=device, dtype=dtype))
+    mod("wan.modules.clip", CLIPModel=type("CLIPModel", (), {}))
+    if "wan.utils" not in sys.modules:
+        m = types.ModuleType("wan.utils")
+        m.__path__ = [os.path.join(REFERENCE_ROOT, "wan", "utils")]
+        sys.modules["wan.utils"] = m
+    from wan.utils.fm_solvers_unipc import FlowUniPCMultistepScheduler
+    from pipeline.causal_diffusion_inference import CausalDiffusionInferencePipeline
+    ns.FlowUniPCMultistepScheduler = FlowUniPCMultistepScheduler
+    ns.CausalDiffusionInferencePipeline = CausalDiffusionInferencePipeline
+    return ns

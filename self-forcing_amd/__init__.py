@@ -18,6 +18,9 @@ from .vae_weights import VaeShape, WAN_VAE, VAE_REDUCED, synth_vae_state_dict, v
 from .vae import WanVAEWrapper, WanVAEDecoder, repack_conv  # noqa: F401
 from .t5_weights import T5Shape, UMT5_XXL, T5_REDUCED, synth_t5_state_dict, t5_param_shapes  # noqa: F401
 from .text_encoder import WanTextEncoder, UMT5Encoder, relative_position_buckets  # noqa: F401
+from . import unipc  # noqa: F401
+from .diffusion_pipeline import CausalDiffusionInferencePipeline  # noqa: F401
+from .unipc import FlowUniPCMultistepScheduler  # noqa: F401
 from . import ops, _lib  # noqa: F401
 
 __all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict",
@@ -26,4 +29,4 @@ __all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "sy
            "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "RolloutPool", "ops",
            "VaeShape", "WAN_VAE", "VAE_REDUCED", "synth_vae_state_dict", "vae_param_shapes", "WanVAEWrapper",
            "WanVAEDecoder", "repack_conv", "T5Shape", "UMT5_XXL", "T5_REDUCED", "synth_t5_state_dict", "t5_param_shapes",
-           "WanTextEncoder", "UMT5Encoder", "relative_position_buckets"]
+           "WanTextEncoder", "UMT5Encoder", "relative_position_buckets", "FlowUniPCMultistepScheduler", "CausalDiffusionInferencePipeline"]

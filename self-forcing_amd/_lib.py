@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # epilogue codes (enum sf_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
@@ -135,6 +135,7 @@ SIGNATURES = {
     "sf_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sf_unpatchify_x0": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_add_noise": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _vp]),
+    "sf_lincomb_bf16": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_float), _i, _i64, _vp]),
     "sf_dit_workspace_bytes": (C.c_size_t, [C.POINTER(Model), _i, _i, _i, _i, _i]),
     "sf_dit_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ForwardArgs), _vp]),
     "sf_conv_igemm": (C.c_int, [C.POINTER(ConvArgs), _vp]),

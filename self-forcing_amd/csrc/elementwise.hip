@@ -302,6 +302,33 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const bf16_t* __restrict
   }
 }
 
+// out[i] = sum_k c[k] x_k[i]: the UniPC predictor / corrector and the classifier-free-guidance blend are linear in
+// their tensors (fm_solvers_unipc.py:350-626, causal_diffusion_inference.py:423-424); the host evaluates the scalars.
+struct LinCombP {
+  const bf16_t* x[SF_LINCOMB_MAX];
+  float c[SF_LINCOMB_MAX];
+  bf16_t* out;
+  long n8;
+  int n_terms;
+};
+template <int NT>
+__global__ __launch_bounds__(256) void lincomb_kernel(const LinCombP p) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n8; i += (long)gridDim.x * blockDim.x) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.x[k] + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = k == 0 ? p.c[0] * (float)v[j] : acc[j] + p.c[k] * (float)v[j];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+    *reinterpret_cast<bf16x8*>(p.out + i * 8) = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void sinusoid_kernel(const void* __restrict__ t, int t_is_i64, bf16_t* __restrict__ out,
                                                        int n, int dim) {
   const int half = dim >> 1;
@@ -458,6 +485,32 @@ extern "C" int sf_add_noise(const void* x0, const void* eps, const void* timeste
   hipLaunchKernelGGL(add_noise_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x0, (const bf16_t*)eps, timestep, t_is_int64,
                      sigmas, timesteps, n_table, (bf16_t*)out, (long)inner);
   SF_HIP_LAUNCH_CHECK("sf_add_noise");
+  return 0;
+}
+
+extern "C" int sf_lincomb_bf16(void* out, const void* const* xs, const float* coefs, int n_terms, int64_t n, void* stream) {
+  SF_CHECK(out && xs && coefs, "sf_lincomb_bf16: null argument");
+  SF_CHECK(n_terms >= 1 && n_terms <= SF_LINCOMB_MAX, "sf_lincomb_bf16: n_terms must be 1..%d, got %d", SF_LINCOMB_MAX, n_terms);
+  SF_CHECK(n > 0 && n % 8 == 0, "sf_lincomb_bf16: element count must be a positive multiple of 8");
+  LinCombP p;
+  for (int k = 0; k < SF_LINCOMB_MAX; ++k) {
+    p.x[k] = k < n_terms ? (const bf16_t*)xs[k] : nullptr;
+    p.c[k] = k < n_terms ? coefs[k] : 0.0f;
+    SF_CHECK(k >= n_terms || xs[k], "sf_lincomb_bf16: null input %d", k);
+  }
+  p.out = (bf16_t*)out;
+  p.n8 = n / 8;
+  p.n_terms = n_terms;
+  const dim3 grid((unsigned)min((long)2048, (p.n8 + 255) / 256)), block(256);
+  switch (n_terms) {
+    case 1: hipLaunchKernelGGL(lincomb_kernel<1>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL(lincomb_kernel<2>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL(lincomb_kernel<3>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 4: hipLaunchKernelGGL(lincomb_kernel<4>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 5: hipLaunchKernelGGL(lincomb_kernel<5>, grid, block, 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL(lincomb_kernel<6>, grid, block, 0, (hipStream_t)stream, p); break;
+  }
+  SF_HIP_LAUNCH_CHECK("sf_lincomb_bf16");
   return 0;
 }
 

@@ -6,6 +6,7 @@ raise if the library is missing -- there is no fallback path.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -211,6 +212,29 @@ def add_noise(x0: Tensor, eps: Tensor, timestep: Tensor, sigmas: Tensor, timeste
     out = torch.empty_like(eps)
     check(lib().sf_add_noise(x0.data_ptr(), eps.data_ptr(), tt.data_ptr(), is64, sigmas.data_ptr(), timesteps.data_ptr(),
                              sigmas.numel(), out.data_ptr(), n, inner, stream_handle()), "sf_add_noise")
+    return out
+
+
+LINCOMB_MAX = 6
+
+
+def lincomb(tensors, coefs, out: Optional[Tensor] = None) -> Tensor:
+    """out = sum_k coefs[k] * tensors[k]: bf16 tensors of one shape, fp32 accumulation, one final rounding (`out` may be
+    one of the inputs).  The tensor arithmetic of the UniPC sampler and of the guidance blend (sf_lincomb_bf16)."""
+    if not 1 <= len(tensors) <= LINCOMB_MAX or len(tensors) != len(coefs):
+        raise ValueError(f"lincomb: 1..{LINCOMB_MAX} tensors with one coefficient each, got {len(tensors)} / {len(coefs)}")
+    xs = [_bf16(t, f"tensors[{i}]").contiguous() for i, t in enumerate(tensors)]
+    for t in xs[1:]:
+        if t.shape != xs[0].shape or t.device != xs[0].device:
+            raise ValueError("lincomb: tensors must share shape and device")
+    if out is None:
+        out = torch.empty_like(xs[0])
+    elif out.shape != xs[0].shape or out.dtype != torch.bfloat16 or not out.is_contiguous():
+        raise ValueError("lincomb: out must be a contiguous bf16 tensor of the inputs' shape")
+    n = len(xs)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    check(lib().sf_lincomb_bf16(out.data_ptr(), ptrs, cf, n, xs[0].numel(), stream_handle()), "sf_lincomb_bf16")
     return out
 
 
