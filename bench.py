@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
     ap.add_argument("--profile", action="store_true", help="print the pipeline's per-chunk event timing")
+    ap.add_argument("--cfg-frames", type=int, default=6,
+                    help="latent frames of the 50-step CFG sampler leg (SURVEY 8f-4); 0 skips it, 21 = the whole clip (~20 s)")
     ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
     a = ap.parse_args()
 
@@ -332,6 +334,35 @@ def main():
             out["streaming"]["overlapped_decode_clip_fps"] = decoded / (time.perf_counter() - t_start)
             out["streaming"]["serial_decode_clip_fps"] = decoded / sum(ts)
             assert n_chunks == len(ts)
+    if rank == 0 and not a.no_roofline and a.cfg_frames > 0:
+        # 50-step UniPC + classifier-free guidance over the same generator: 2 x 50 + 2 forwards per chunk
+        log("cfg sampler leg")
+        cargs = SimpleNamespace(num_train_timestep=1000, timestep_shift=shift, independent_first_frame=False,
+                                num_frame_per_block=nfpb, negative_prompt="synthetic negative prompt", guidance_scale=3.0)
+        cfg_frames = max(nfpb, a.cfg_frames // nfpb * nfpb)
+        cfg_res = {}
+        for overlap in (True, False):
+            cpipe = sfa.CausalDiffusionInferencePipeline(cargs, dev, generator=gen, text_encoder=enc, vae=sfa.IdentityVAE(),
+                                                         overlap_cfg=overlap)
+            cnoise = torch.randn([1, cfg_frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
+            cpipe.sampling_steps = 2
+            cpipe.inference(cnoise, [prompts[0]], None, None, None)          # caches + workspaces
+            cpipe.sampling_steps = 50
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            clat = cpipe.inference(cnoise, [prompts[0]], None, None, None, return_latents=True)[1]
+            torch.cuda.synchronize()
+            cfg_res[overlap] = time.perf_counter() - tc
+            assert torch.isfinite(clat.float()).all()
+            del cpipe
+        n_fw = (cfg_frames // nfpb) * (2 * 50 + 2)
+        cdec = DECODED_PER_LATENT(cfg_frames)
+        out["cfg_sampler"] = {"latent_frames": cfg_frames, "decoded_frames": cdec, "forwards": n_fw, "sampling_steps": 50,
+                              "guidance_scale": 3.0, "seconds": cfg_res[True], "seconds_one_stream": cfg_res[False],
+                              "ms_per_forward": 1e3 * cfg_res[True] / n_fw, "frames_per_s": cdec / cfg_res[True],
+                              "note": "CausalDiffusionInferencePipeline: UniPC (order 2) + guidance, prompt / negative-prompt "
+                                      "passes on two HIP streams (`seconds_one_stream`: back to back); first "
+                                      f"{cfg_frames} latent frames of a clip, so the cache is at most {cfg_frames * fs} tokens long"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(shape, sd, 1, nfpb, len(step_list), a.frames)
     if dist is not None:
