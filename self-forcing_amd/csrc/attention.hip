@@ -28,10 +28,12 @@
 #define SF_R64_INC "attention_r64_asm.inc"   // timing-only ablation builds substitute their own (tools/gen_attention_r64.py --abl)
 #endif
 #include SF_R64_INC
+#ifdef SF_WITH_WS_KERNEL                     // experimental warp-specialised structure: tools/probes/build_ws_abl.sh only
 #ifndef SF_WS_INC
 #define SF_WS_INC "attention_ws_asm.inc"    // tools/gen_attention_ws.py
 #endif
 #include SF_WS_INC
+#endif
 
 namespace {
 
@@ -728,6 +730,7 @@ __global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
 }
 
 
+#ifdef SF_WITH_WS_KERNEL
 // ------------------------------------------------------------------------------------------
 // Warp-specialised structure: the 64 query rows of a wave pair are split by ROLE instead of by rows -- waves
 // 0-3 compute scores and softmax (role A), waves 4-7, which share the SIMDs with them pairwise, the P.V products,
@@ -817,6 +820,8 @@ __global__ __launch_bounds__(512) void attention_ws_kernel(AttP p) {
 }
 
 
+#endif  // SF_WITH_WS_KERNEL
+
 }  // namespace
 
 extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
@@ -842,6 +847,7 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   // short ones (cross-attention: 8 key tiles) the 8-wave anti-phase kernel; small problems the 4-wave one.
   // Environment switches (A/B timing and tests only): SF_ATTN_R64 / SF_ATTN_W8 / SF_ATTN_W4 force a structure.
   const long nwg64 = (long)((Lq + QT64 - 1) / QT64) * H * B;
+#ifdef SF_WITH_WS_KERNEL
   if (getenv("SF_ATTN_WS")) {   // bring-up switch of the warp-specialised kernel
     p.q_tiles = (Lq + QT64 - 1) / QT64;
     static bool attr_ws = false;
@@ -853,6 +859,7 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
     SF_HIP_LAUNCH_CHECK("sf_attention");
     return 0;
   }
+#endif
   const bool forced = getenv("SF_ATTN_W8") || getenv("SF_ATTN_W4");
   if (getenv("SF_ATTN_R64") || (!forced && nwg64 >= 192 && Lk > 1024)) {
     p.q_tiles = (Lq + QT64 - 1) / QT64;

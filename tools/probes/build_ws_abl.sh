@@ -1,6 +1,8 @@
 #!/bin/bash
 # Timing-only variants of the warp-specialised attention kernel: build_ws_abl.sh NAME ABL[,ABL...] ...
-# (ablations of tools/gen_attention_ws.py: nosoftmax nodma nobarrier nopv noqk).  Select with SF_HIP_LIB.
+# (ablations of tools/gen_attention_ws.py: nosoftmax nodma nobarrier nopv noqk; pass "" for the full kernel).
+# The shipped library does not contain this kernel (-DSF_WITH_WS_KERNEL here only); select a variant with
+# SF_HIP_LIB=tools/probes/abl/libabl_NAME.so SF_ATTN_WS=1.
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 cd "$ROOT/self-forcing_amd/csrc"
@@ -10,7 +12,7 @@ while [ $# -ge 2 ]; do
   name=$1; abl=$2; shift 2
   python "$ROOT/tools/gen_attention_ws.py" --abl "$abl" --out /tmp/ws_$name.inc > /dev/null
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function \
-     -fno-honor-nans -fno-honor-infinities -DSF_WS_INC="\"/tmp/ws_$name.inc\"" -c attention.hip -o /tmp/abl_att_$name.o
+     -fno-honor-nans -fno-honor-infinities -DSF_WITH_WS_KERNEL -DSF_WS_INC="\"/tmp/ws_$name.inc\"" -c attention.hip -o /tmp/abl_att_$name.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 gemm_bf16.o /tmp/abl_att_$name.o elementwise.o \
      small_linear.o dit_forward.o conv_igemm.o vae_elementwise.o vae_decode.o t5_encoder.o capi.o -o "$ROOT/tools/probes/abl/libabl_$name.so"
   echo built $name
