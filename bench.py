@@ -364,7 +364,7 @@ def main():
                                       "passes on two HIP streams (`seconds_one_stream`: back to back); first "
                                       f"{cfg_frames} latent frames of a clip, so the cache is at most {cfg_frames * fs} tokens long"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_leg(shape, sd, 1, nfpb, len(step_list), a.frames)
+        out["cpu_baseline"] = cpu_baseline_leg(shape, sd, nfpb, nfpb, len(step_list), a.frames)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

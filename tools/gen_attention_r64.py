@@ -311,7 +311,20 @@ def phase(mfmas, others):
     for i, (text, needs) in enumerate(mfmas):
         for tg in needs:
             lds.need(tags[tg])
-        e(text)
+        if "mfma16" in ABL:    # timing only: the same flops as two 16x16x32 instructions (numerically meaningless)
+            import re
+            mm = re.match(r"v_mfma_f32_32x32x16_bf16 ([av])\[(\d+):\d+\], (\S+), (\S+), (\S+)$", text)
+            kind, lo, a_op, b_op, c_op = mm.group(1), int(mm.group(2)), mm.group(3), mm.group(4), mm.group(5)
+            for h in range(2):
+                acc = f"{kind}[{lo + 4 * h}:{lo + 4 * h + 3}]"
+                if c_op == "0":
+                    c = "0"
+                else:
+                    cm = re.match(r"([av])\[(\d+):\d+\]", c_op)
+                    c = f"{cm.group(1)}[{int(cm.group(2)) + 4 * h}:{int(cm.group(2)) + 4 * h + 3}]"
+                e(f"v_mfma_f32_16x16x32_bf16 {acc}, {a_op}, {b_op}, {c}")
+        else:
+            e(text)
         for _ in range(per[i]):
             emit_other(others[oi])
             oi += 1
