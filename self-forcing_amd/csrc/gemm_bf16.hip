@@ -325,6 +325,7 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
   stage(0, 0);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+  bf16x8 xf0[8], wf0[4], xf1[8], wf1[4];
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const char* buf = smem + cur * BIG_STAGE;
@@ -332,11 +333,16 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
     // the next tile} (see gemm_bf16_kernel), then the second sub-step's 32 MFMAs
     const int kn = min(kt + 1, nk - 1) * BK;
     char* sbase = smem + (cur ^ 1) * BIG_STAGE + wave * 4096;
-    bf16x8 xf0[8], wf0[4], xf1[8], wf1[4];
+#ifdef SF_ABL_BIG_NOREAD0   // timing only: the up-front fragment reads of the first sub-step
+    if (kt == 0) {
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff[0]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff[0]);
+#ifdef SF_ABL_BIG_NOREAD0
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -358,7 +364,11 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
       for (int nt = 0; nt < 4; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef SF_ABL_BIG_NOBAR     // timing only: no workgroup barrier (each wave still waits for its own LDS-DMA)
+    __builtin_amdgcn_s_waitcnt(0);
+#else
     __syncthreads();
+#endif
   }
   const int mrow = m0 + wr * 128 + (lane & 15);
   const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
