@@ -14,7 +14,9 @@ one barrier after set-up.  It writes LATENTS (`<idx>-<sample>.pt`) and, when a V
 video as a uint8 tensor [T, H, W, 3] (`<idx>-<sample>.video.pt`: what the reference hands to
 `write_video`, inference.py:186-196; there is no video encoder in this image).  The umT5 encoder is
 outside this path, so embeddings are synthetic unless `--prompt_embeds` (a .pt dict prompt -> [L, 4096]
-tensor) is given.
+tensor) is given.  A config WITHOUT `denoising_step_list` selects the multi-step classifier-free-guidance sampler
+(`CausalDiffusionInferencePipeline`), as inference.py:62-67 does; it needs `num_train_timestep`, `timestep_shift`,
+`guidance_scale` and `negative_prompt`.
 """
 import argparse
 import os
@@ -62,6 +64,7 @@ def main():
     ap.add_argument("--latent_height", type=int, default=60)
     ap.add_argument("--latent_width", type=int, default=104)
     ap.add_argument("--vae_path", default=None, help="Wan2.1_VAE.pth: decode the latents to pixels")
+    ap.add_argument("--sampling_steps", type=int, default=0, help="multi-step sampler only: override its 50 steps")
     ap.add_argument("--vae_random_init_seed", type=int, default=None, help="seeded random VAE decoder weights instead")
     a = ap.parse_args()
 
@@ -79,8 +82,6 @@ def main():
     torch.set_grad_enabled(False)
 
     cfg = load_config(a.config_path, a.default_config_path)
-    if not is_few_step(cfg):
-        raise SystemExit("config has no denoising_step_list: the multi-step CFG sampler is not part of this path")
     kwargs = dict(cfg.get("model_kwargs") or {})
     if a.checkpoint_path:
         if a.checkpoint_path.endswith(".safetensors"):
@@ -104,7 +105,16 @@ def main():
     elif a.vae_random_init_seed is not None:
         vae = sfa.WanVAEWrapper(sfa.synth_vae_state_dict(sfa.WAN_VAE, seed=a.vae_random_init_seed), device=device)
     decode = not isinstance(vae, sfa.IdentityVAE)
-    pipe = sfa.CausalInferencePipeline(cfg, device, generator=gen, text_encoder=enc, vae=vae)
+    few_step = is_few_step(cfg)        # inference.py:62-67: few-step rollout iff the config has denoising_step_list
+    if few_step:
+        pipe = sfa.CausalInferencePipeline(cfg, device, generator=gen, text_encoder=enc, vae=vae)
+    else:                              # 50-step UniPC sampler with classifier-free guidance
+        for key in ("num_train_timestep", "timestep_shift", "guidance_scale", "negative_prompt"):
+            if key not in cfg:
+                raise SystemExit(f"config has neither denoising_step_list nor {key}: cannot build a sampler from it")
+        pipe = sfa.CausalDiffusionInferencePipeline(cfg, device, generator=gen, text_encoder=enc, vae=vae)
+        if a.sampling_steps:
+            pipe.sampling_steps = a.sampling_steps
 
     if rank == 0:
         os.makedirs(a.output_folder, exist_ok=True)
@@ -114,7 +124,10 @@ def main():
     for idx in shard_indices(len(prompts), rank, world):
         noise = torch.randn([a.num_samples, a.num_output_frames, 16, a.latent_height, a.latent_width], device=device,
                             dtype=torch.bfloat16)
-        video, latents = pipe.inference(noise=noise, text_prompts=[prompts[idx]] * a.num_samples, return_latents=True)
+        if few_step:
+            video, latents = pipe.inference(noise=noise, text_prompts=[prompts[idx]] * a.num_samples, return_latents=True)
+        else:
+            video, latents = pipe.inference(noise, [prompts[idx]] * a.num_samples, None, None, None, return_latents=True)
         for s in range(a.num_samples):
             torch.save(latents[s].cpu(), os.path.join(a.output_folder, f"{idx}-{s}.pt"))
             if decode:   # [T, 3, H, W] in [0, 1] -> [T, H, W, 3] uint8 (inference.py:186-187)

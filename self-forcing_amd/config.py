@@ -63,5 +63,5 @@ def load_config(path: Optional[str] = None, default_path: Optional[str] = None, 
 
 def is_few_step(cfg: Config) -> bool:
     """Pipeline selection of the reference: few-step iff `denoising_step_list` is present
-    (inference.py:62-67).  Only the few-step causal pipeline exists here."""
+    (inference.py:62-67); otherwise the multi-step CFG sampler (`CausalDiffusionInferencePipeline`)."""
     return "denoising_step_list" in cfg

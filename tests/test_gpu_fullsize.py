@@ -131,3 +131,33 @@ def test_generate_cli_reduced(tmp_path):
     noise = torch.randn([1, 2, 16, 8, 12], device=DEV, dtype=torch.bfloat16)
     lat = pipe.inference(noise, ["a red fox"], return_latents=True)[1]
     assert torch.equal(lat[0].cpu(), a)
+
+
+def test_generate_cli_multistep_sampler(tmp_path):
+    """A config without denoising_step_list (the reference's configs/tiny_test.yaml keys) selects the multi-step
+    classifier-free-guidance sampler, as inference.py:62-67 does."""
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(open(os.path.join(ROOT, "configs", "tiny_test_multistep.yaml")).read().replace(
+        "model_kwargs: {}", "model_kwargs:\n  model_name: reduced\n  timestep_shift: 8.0\n"))
+    prompts = tmp_path / "p.txt"
+    prompts.write_text("a red fox\n")
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "generate.py"), "--config_path", str(cfg), "--data_path", str(prompts),
+           "--output_folder", str(out), "--random_init_seed", "0", "--num_output_frames", "3", "--latent_height", "8",
+           "--latent_width", "12", "--seed", "5", "--sampling_steps", "6"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    a = torch.load(out / "0-0.pt")
+    assert a.shape == (3, 16, 8, 12) and torch.isfinite(a.float()).all()
+    # same seed in process -> same latents (chunks [1, 1, 1]: independent first frame, 1 frame per block)
+    torch.manual_seed(5)
+    gen = sfa.WanDiffusionWrapper(model_name="reduced", timestep_shift=8.0, is_causal=True, random_init_seed=0, device=DEV)
+    enc = sfa.SyntheticTextEncoder(512, sfa.WAN_REDUCED.text_dim, device=DEV)
+    from types import SimpleNamespace
+    args = SimpleNamespace(num_train_timestep=1000, timestep_shift=8.0, independent_first_frame=True, num_frame_per_block=1,
+                           negative_prompt="", guidance_scale=7.5)
+    pipe = sfa.CausalDiffusionInferencePipeline(args, DEV, generator=gen, text_encoder=enc, vae=sfa.IdentityVAE())
+    pipe.sampling_steps = 6
+    noise = torch.randn([1, 3, 16, 8, 12], device=DEV, dtype=torch.bfloat16)
+    lat = pipe.inference(noise, ["a red fox"], None, None, None, return_latents=True)[1]
+    assert torch.equal(lat[0].cpu(), a)
