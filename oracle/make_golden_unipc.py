@@ -75,7 +75,11 @@ ROLLOUTS = {
     "cfg_nfpb3": (3, False, 5.0, 3.0, 50, 6, 0),
     "cfg_iff": (3, True, 8.0, 5.0, 10, 4, 0),
     "cfg_ext": (3, False, 5.0, 6.0, 12, 3, 3),
+    # start_frame_index = 2 (long-video window, causal_diffusion_inference.py:183, :234): RoPE positions and the
+    # cache write position start two frames in, the first two frames' cache rows stay zero and ARE attended to
+    "cfg_start2": (1, False, 5.0, 4.0, 8, 2, 0),
 }
+START_FRAME = {"cfg_start2": 2}
 
 
 def run_reference(ns, shape, sd, dtype, name, noise, pe, ne, initial):
@@ -97,12 +101,13 @@ def run_reference(ns, shape, sd, dtype, name, noise, pe, ne, initial):
     pipe.num_transformer_blocks = shape.num_layers
     pipe.frame_seq_length = fs
     pipe.sampling_steps = steps
-    tokens = (nfr + nin) * fs
+    tokens = (nfr + nin + START_FRAME.get(name, 0)) * fs
     pipe.kv_cache_pos, pipe.crossattn_cache_pos = fresh_caches(shape, noise.shape[0], tokens, dtype)
     pipe.kv_cache_neg, pipe.crossattn_cache_neg = fresh_caches(shape, noise.shape[0], tokens, dtype)
     with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink), torch.no_grad():
         _, lat = pipe.inference(noise.to(dtype), ["p"] * noise.shape[0], None, None, None,
-                                initial_latent=None if initial is None else initial.to(dtype), return_latents=True)
+                                initial_latent=None if initial is None else initial.to(dtype), return_latents=True,
+                                start_frame_index=START_FRAME.get(name, 0))
     return lat, pipe.kv_cache_pos, pipe.kv_cache_neg
 
 

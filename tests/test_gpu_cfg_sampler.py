@@ -115,7 +115,9 @@ ROLLOUTS = {   # name: (nfpb, independent_first_frame, shift, guidance, sampling
     "cfg_nfpb3": (3, False, 5.0, 3.0, 50),
     "cfg_iff": (3, True, 8.0, 5.0, 10),
     "cfg_ext": (3, False, 5.0, 6.0, 12),
+    "cfg_start2": (1, False, 5.0, 4.0, 8),      # start_frame_index = 2
 }
+START_FRAME = {"cfg_start2": 2}
 
 
 class TwoPromptEncoder:
@@ -150,7 +152,9 @@ def test_cfg_rollout_vs_reference_golden(sd_reduced, name, overlap):
     pipe = make_pipe(sd_reduced, R, name, overlap)
     noise = T(R[f"{name}_noise"]).bfloat16().to(DEV)
     initial = T(R[f"{name}_initial"]).bfloat16().to(DEV) if f"{name}_initial" in R else None
-    video, lat = pipe.inference(noise, ["p"], None, None, None, initial_latent=initial, return_latents=True)
+    start = START_FRAME.get(name, 0)
+    video, lat = pipe.inference(noise, ["p"], None, None, None, initial_latent=initial, return_latents=True,
+                                start_frame_index=start)
     torch.cuda.synchronize()
     want = T(R[f"{name}_lat_f32"])
     ref_noise = rel(T(R[f"{name}_lat_bf16"]), want)           # the reference's own bf16 path vs its fp32 math
@@ -160,7 +164,8 @@ def test_cfg_rollout_vs_reference_golden(sd_reduced, name, overlap):
     assert int(pipe.kv_cache_pos[0]["local_end_index"]) == int(R[f"{name}_local_end"])
     assert int(pipe.kv_cache_neg[-1]["global_end_index"]) == int(R[f"{name}_global_end"])
     # second call on the same pipeline: the reset branch (causal_diffusion_inference.py:215-231) reproduces it
-    _, lat2 = pipe.inference(noise, ["p"], None, None, None, initial_latent=initial, return_latents=True)
+    _, lat2 = pipe.inference(noise, ["p"], None, None, None, initial_latent=initial, return_latents=True,
+                             start_frame_index=start)
     assert torch.equal(lat, lat2)
 
 
@@ -205,3 +210,25 @@ def test_cfg_rollout_vs_oracle_with_pose_tokens():
         pipe.inference(noise.to(DEV), ["p"], None, None, None, dwpose_data_emb=pose[:, :, :1].to(DEV))
     with pytest.raises(NotImplementedError):
         pipe.inference(noise.to(DEV), ["p"], object(), None, None)
+
+
+def test_cfg_rollout_batch2_matches_per_sample(sd_reduced):
+    """Two prompts in one call (two cache rows per layer, shared scheduler scalars) == each prompt alone."""
+    shape = sfa.WAN_REDUCED
+    g = torch.Generator().manual_seed(123)
+    noise = torch.randn(2, 2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(2, 512, shape.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    ne = torch.randn(2, 512, shape.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    args = SimpleNamespace(num_train_timestep=1000, timestep_shift=5.0, independent_first_frame=False,
+                           num_frame_per_block=1, negative_prompt="NEG", guidance_scale=3.0)
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd_reduced, timestep_shift=5.0, is_causal=True, device=DEV)
+
+    def run(rows):
+        pipe = sfa.CausalDiffusionInferencePipeline(args, DEV, generator=gen, text_encoder=TwoPromptEncoder(pe[rows], ne[rows]),
+                                                    vae=sfa.IdentityVAE())
+        pipe.sampling_steps = 5
+        return pipe.inference(noise[rows].contiguous(), ["p"] * len(rows), None, None, None, return_latents=True)[1]
+
+    both = run([0, 1])
+    for i in range(2):
+        assert rel(both[i:i + 1], run([i])) < 1e-6

@@ -28,7 +28,9 @@ ROLLOUTS = {
     "cfg_nfpb3": (3, False, 5.0, 3.0, 50),
     "cfg_iff": (3, True, 8.0, 5.0, 10),
     "cfg_ext": (3, False, 5.0, 6.0, 12),
+    "cfg_start2": (1, False, 5.0, 4.0, 8),      # start_frame_index = 2
 }
+START_FRAME = {"cfg_start2": 2}
 
 
 def T(a, dtype=torch.float32):
@@ -132,8 +134,11 @@ def test_oracle_cfg_rollout(weights, name, tag):
     args = uo.CfgRolloutArgs(num_frame_per_block=nfpb, independent_first_frame=iff, timestep_shift=shift,
                              guidance_scale=g, sampling_steps=nsteps)
     initial = T(R[f"{name}_initial"]).to(dt) if f"{name}_initial" in R else None
-    lat = uo.cfg_rollout(W, cfg, args, T(R[f"{name}_noise"]).to(dt), T(R[f"{name}_pe"]).to(dt),
-                         T(R[f"{name}_ne"]).to(dt), initial)
+    start = START_FRAME.get(name, 0)
+    noise = T(R[f"{name}_noise"]).to(dt)
+    tokens = (noise.shape[1] + (0 if initial is None else initial.shape[1]) + start) * (LAT_H // 2) * (LAT_W // 2)
+    lat = uo.cfg_rollout(W, cfg, args, noise, T(R[f"{name}_pe"]).to(dt), T(R[f"{name}_ne"]).to(dt), initial,
+                         cache_tokens=tokens, start_frame_index=start)
     # bf16: the reference's own bf16-vs-fp32 distance on these rollouts is 0.9-2.7e-2 (guidance amplifies the
     # rounding of 100 forwards per chunk); two bf16 implementations agree to about that
     tol = 5e-6 if tag == "f32" else 2.5e-2
