@@ -63,15 +63,18 @@ def usable_cores():
     return n
 
 
-def rollout_flops(shape, frames, nfpb, n_steps, fs):
+def rollout_flops(shape, frames, nfpb, n_steps, fs, window_frames=0):
     """Algorithmic FLOPs of one rollout: linear + cross-attn per token, self-attn
-    4*C*N*Lk per layer per forward; (n_steps + 1) forwards per chunk."""
+    4*C*N*Lk per layer per forward; (n_steps + 1) forwards per chunk.  `window_frames` > 0: rolling-window mode,
+    the keys a chunk attends to are capped at that many frames (causal_model.py:203-231)."""
     C, Fd, L = shape.dim, shape.ffn_dim, shape.num_layers
     per_tok = L * (12 * C * C + 4 * C * Fd + 4 * shape.text_len * C) + 2 * 64 * C + 2 * C * 64
     total = 0.0
     n = nfpb * fs
     for chunk in range(frames // nfpb):
         lk = (chunk + 1) * n
+        if window_frames > 0:
+            lk = min(lk, window_frames * fs)
         total += (n_steps + 1) * (per_tok * n + L * 4.0 * C * n * lk)
     return total
 
@@ -88,7 +91,7 @@ def time_kernel(fn, iters):
     return e0.elapsed_time(e1) / iters  # ms
 
 
-def roofline_leg(shape, dev, frames, nfpb, fs):
+def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
     """Average launch duration of the self-attention kernel over the Lk values one rollout visits
     (each chunk index launches it equally often), and of the biggest GEMM, from events on the
     launch stream."""
@@ -96,12 +99,12 @@ def roofline_leg(shape, dev, frames, nfpb, fs):
     n = nfpb * fs
     g = torch.Generator(device="cpu").manual_seed(1)
     q = torch.randn(1, n, H, 128, generator=g).to(torch.bfloat16).to(dev)
-    lk_max = frames * fs
+    lk_max = (min(frames, window_frames) if window_frames > 0 else frames) * fs
     k = torch.randn(1, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
     v = torch.randn(1, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
     durs, flops = [], []
     for chunk in range(frames // nfpb):
-        lk = (chunk + 1) * n
+        lk = min((chunk + 1) * n, lk_max)
         ms = time_kernel(lambda: ops.attention(q, k[:, :lk], v[:, :lk]), 10)
         durs.append(ms)
         flops.append(4.0 * shape.dim * n * lk)
@@ -118,7 +121,7 @@ def roofline_leg(shape, dev, frames, nfpb, fs):
            "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the same 7 cache lengths)",
            "avg_launch_ms": avg_ms, "flops_per_launch": avg_flops,
-           "per_lk_tflops": {str((i + 1) * n): flops[i] / (durs[i] * 1e-3) / 1e12 for i in range(len(durs))}}
+           "per_lk_tflops": {str(min((i + 1) * n, lk_max)): flops[i] / (durs[i] * 1e-3) / 1e12 for i in range(len(durs))}}
     # GEMMs: ffn.0 (N = ffn_dim) and ffn.2 (K = ffn_dim) at M = n
     a = torch.randn(n, shape.dim, generator=g).to(torch.bfloat16).to(dev)
     w1 = (torch.randn(shape.ffn_dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
@@ -177,6 +180,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
     ap.add_argument("--profile", action="store_true", help="print the pipeline's per-chunk event timing")
+    ap.add_argument("--local-attn-size", type=int, default=-1,
+                    help="rolling-window mode: KV cache of this many latent frames (long rollouts, BASELINE configs[3]); -1 = global")
+    ap.add_argument("--sink-size", type=int, default=0, help="frames kept at the head of the rolling window")
     ap.add_argument("--cfg-frames", type=int, default=6,
                     help="latent frames of the 50-step CFG sampler leg (SURVEY 8f-4); 0 skips it, 21 = the whole clip (~20 s)")
     ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
@@ -202,7 +208,9 @@ def main():
     sd = sfa.synth_state_dict(shape, seed=0)                    # identical on every rank
     args = SimpleNamespace(denoising_step_list=step_list, warp_denoising_step=True, independent_first_frame=False,
                            num_frame_per_block=nfpb, context_noise=0)
-    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=shift, is_causal=True, device=dev)
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=shift, is_causal=True, device=dev,
+                                  local_attn_size=a.local_attn_size, sink_size=a.sink_size)
+    window = a.local_attn_size if a.local_attn_size > 0 else 0
     enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=dev)
     pool = sfa.RolloutPool(args, dev, gen, lambda: enc, sfa.IdentityVAE, streams=a.streams)
 
@@ -252,7 +260,7 @@ def main():
 
     decoded = DECODED_PER_LATENT(a.frames)
     fps = world * a.steps * decoded / elapsed
-    flops = rollout_flops(shape, a.frames, nfpb, len(step_list), fs)
+    flops = rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window)
     out = {
         "metric": "decoded frames/sec/node, Wan-1.3B 832x480 4-step AR rollout",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -260,7 +268,8 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"S1: {a.model}-shape random-init weights, latent {a.frames}x16x{LAT_H}x{LAT_W} "
                                f"({decoded} decoded frames), {nfpb} frames/chunk, steps {step_list} warped (shift {shift}) "
-                               f"+ 1 context pass per chunk, batch 1 per rollout, {a.streams} rollout(s) in flight per GPU "
+                               f"+ 1 context pass per chunk, " + (f"rolling KV window of {window} frames (sink {a.sink_size}), " if window else "")
+                               + f"batch 1 per rollout, {a.streams} rollout(s) in flight per GPU "
                                f"(one HIP stream each, shared weights), prompts sharded rank::N",
                    "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
                    "parallelism": f"prompt-sharded x{world}", "streams_per_gpu": a.streams},
@@ -270,7 +279,7 @@ def main():
     }
     if rank == 0 and not a.no_roofline:
         log("roofline leg")
-        att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs)
+        att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs, window)
         out["roofline"] = att
         out["gemm"] = gemm
     if rank == 0 and not a.no_vae:
