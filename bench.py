@@ -170,6 +170,7 @@ def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
 
 
 def main():
+    global LAT_H, LAT_W
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -180,6 +181,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE-decode leg")
     ap.add_argument("--profile", action="store_true", help="print the pipeline's per-chunk event timing")
+    ap.add_argument("--latent-height", type=int, default=LAT_H, help="latent rows (60 = 480 px; 90 = 720 px)")
+    ap.add_argument("--latent-width", type=int, default=LAT_W, help="latent columns (104 = 832 px; 160 = 1280 px)")
     ap.add_argument("--local-attn-size", type=int, default=-1,
                     help="rolling-window mode: KV cache of this many latent frames (long rollouts, BASELINE configs[3]); -1 = global")
     ap.add_argument("--sink-size", type=int, default=0, help="frames kept at the head of the rolling window")
@@ -187,6 +190,7 @@ def main():
                     help="latent frames of the 50-step CFG sampler leg (SURVEY 8f-4); 0 skips it, 21 = the whole clip (~20 s)")
     ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
     a = ap.parse_args()
+    LAT_H, LAT_W = a.latent_height, a.latent_width
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,7 +266,8 @@ def main():
     fps = world * a.steps * decoded / elapsed
     flops = rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window)
     out = {
-        "metric": "decoded frames/sec/node, Wan-1.3B 832x480 4-step AR rollout",
+        "metric": "decoded frames/sec/node, Wan-1.3B 832x480 4-step AR rollout" if (a.model, LAT_H, LAT_W) == ("Wan2.1-T2V-1.3B", 60, 104)
+                  else f"decoded frames/sec/node, {a.model} {8 * LAT_W}x{8 * LAT_H} 4-step AR rollout",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
