@@ -255,7 +255,9 @@ def sum_items(sbuf):
     """row sums of the p values left in S[sbuf] (done under the P.V MFMAs).  Plain v_add_f32, pairwise tree in
     place (the p values are dead once converted): packed fp32 instructions (v_pk_add_f32) do NOT execute
     beside MFMAs -- 48 of them between 8 MFMAs cost 139 ns on top of the MFMAs' 130 ns, 48 v_add_f32 cost 3 ns
-    (tools/probes/overlap_probe.hip) -- so the 16 packed adds of the first version cost 65 us per launch."""
+    (tools/probes/overlap_probe.hip) -- so the 16 packed adds of the first version cost 65 us per launch.  Nor does
+    v_dot2c_f32_bf16 acc, P_pair, (1.0, 1.0) on the bf16 P fragments (32 instead of 64 instructions per tile): measured
+    1.5-2.5 % SLOWER than this tree at Lk = 32760."""
     if "nosoftmax" in ABL or "nosum" in ABL:
         return []
     it = []
