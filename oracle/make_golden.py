@@ -382,6 +382,56 @@ def gen_full(ns):
     print("full_1p3b.npz", len(out), "arrays")
 
 
+def gen_tconfig(ns):
+    """BASELINE configs[0] ("T"): the reference's CausalInferencePipeline at the FULL Wan-1.3B shape,
+    configs/tiny_test.yaml + the few-step keys (steps [1000, 750, 500, 250] warped, independent_first_frame,
+    1 frame per block, wrapper-default timestep_shift 8.0), noise [1, 2, 16, 60, 104] => chunks [1, 1] = 2 x (4 + 1)
+    forwards of 1560 tokens; one prompt.  Re-noise tensors injected (pre-drawn), bf16 as shipped and the fp32 math
+    variant.  Stored: inputs' seed, the latents of both variants, every 8th KV row of one head of the first / last layer."""
+    import time
+    shape = sfa.WAN_1_3B
+    sd = sfa.synth_state_dict(shape, seed=0)
+    H, W = 60, 104
+    fs = (H // 2) * (W // 2)
+    g = torch.Generator().manual_seed(4242)
+    noise = bf16_randn((1, 2, 16, H, W), g)
+    pe = bf16_randn((1, 512, shape.text_dim), g)
+    pe[:, 93:] = 0
+    eps = [bf16_randn((1, 16, H, W), g) for _ in range(6)]
+    out = {"weights_seed": np.array(0), "input_seed": np.array(4242), "noise_checksum": np.array(noise.double().sum().item()),
+           "pe_checksum": np.array(pe.double().sum().item()), "eps_checksum": np.array(sum(e.double().sum().item() for e in eps))}
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                                 independent_first_frame=True, num_frame_per_block=1, context_noise=0, model_kwargs={})
+    for tag, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        t0 = time.time()
+        model = build_model(ns, shape, sd, dtype)
+        wrapper = ref_shim.build_wrapper(ns, model, 8.0)
+        sink_out = io.StringIO()
+        with contextlib.redirect_stdout(sink_out):
+            pipe = ns.CausalInferencePipeline(args, device="cpu", generator=wrapper,
+                                              text_encoder=lambda text_prompts: {"prompt_embeds": pe.to(dtype)},
+                                              vae=_IdentityVAE())
+        pipe.kv_cache1, pipe.crossattn_cache = fresh_caches(shape, 1, 2 * fs, dtype)
+        queue = list(eps)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, *a, **kw: queue.pop(0).to(t.dtype).reshape(t.shape)
+        try:
+            with contextlib.redirect_stdout(sink_out), torch.no_grad():
+                _, lat = pipe.inference(noise.to(dtype), ["p"], return_latents=True)
+        finally:
+            torch.randn_like = orig
+        assert not queue
+        out[f"lat_{tag}"] = f32(lat)
+        out[f"k0_head3_{tag}"] = f32(pipe.kv_cache1[0]["k"][0, ::8, 3])      # every 8th cache row
+        out[f"v29_head7_{tag}"] = f32(pipe.kv_cache1[29]["v"][0, ::8, 7])
+        print("tconfig", tag, "latents rms %.4f" % lat.float().pow(2).mean().sqrt().item(), "%.0f s" % (time.time() - t0))
+        del model, wrapper, pipe
+    d = np.linalg.norm(out["lat_bf16"] - out["lat_f32"]) / np.linalg.norm(out["lat_f32"])
+    print("tconfig: reference bf16 vs fp32 rel err %.4f" % d)
+    np.savez_compressed(os.path.join(GOLD, "tconfig_1p3b.npz"), **out)
+    print("tconfig_1p3b.npz", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -400,6 +450,8 @@ def main():
             gen_rollouts(ns)
         if "full" in todo:
             gen_full(ns)
+        if "tconfig" in todo:
+            gen_tconfig(ns)
 
 
 if __name__ == "__main__":

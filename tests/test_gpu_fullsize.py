@@ -161,3 +161,43 @@ def test_generate_cli_multistep_sampler(tmp_path):
     noise = torch.randn([1, 3, 16, 8, 12], device=DEV, dtype=torch.bfloat16)
     lat = pipe.inference(noise, ["a red fox"], None, None, None, return_latents=True)[1]
     assert torch.equal(lat[0].cpu(), a)
+
+
+def _tconfig_inputs():
+    """The seeded inputs of oracle/make_golden.py::gen_tconfig (checked against the checksums the fixture holds)."""
+    import numpy as np
+    G = np.load(os.path.join(ROOT, "tests", "golden", "tconfig_1p3b.npz"))
+    g = torch.Generator().manual_seed(int(G["input_seed"]))
+    bf = lambda shape: torch.randn(shape, generator=g).to(torch.bfloat16)  # noqa: E731
+    noise = bf((1, 2, 16, 60, 104))
+    pe = bf((1, 512, sfa.WAN_1_3B.text_dim))
+    pe[:, 93:] = 0
+    eps = [bf((1, 16, 60, 104)) for _ in range(6)]
+    assert noise.double().sum().item() == float(G["noise_checksum"]) and pe.double().sum().item() == float(G["pe_checksum"]) \
+        and sum(e.double().sum().item() for e in eps) == float(G["eps_checksum"]), \
+        "torch CPU generator stream changed; regenerate the fixture"
+    return G, noise, pe, eps
+
+
+def test_tconfig_rollout_vs_reference_golden(sd_1p3b):
+    """BASELINE configs[0] at the FULL Wan-1.3B shape: the reference's own CausalInferencePipeline run
+    (configs/tiny_test.yaml + few-step keys: independent first frame, 1 frame per block, shift 8, 2 chunks x (4 + 1)
+    forwards of 1560 tokens) against the HIP path on the same weights, noise, prompt embedding and re-noise draws."""
+    G, noise, pe, eps = _tconfig_inputs()
+    T = lambda a: torch.from_numpy(a)  # noqa: E731
+    args = SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                           independent_first_frame=True, num_frame_per_block=1, context_noise=0)
+    gen = sfa.WanDiffusionWrapper(shape=sfa.WAN_1_3B, state_dict=sd_1p3b, timestep_shift=8.0, is_causal=True, device=DEV)
+    pipe = sfa.CausalInferencePipeline(args, DEV, generator=gen, text_encoder=sfa.FixedTextEncoder(pe.to(DEV)), vae=sfa.IdentityVAE())
+    q = list(eps)
+    pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+    lat = pipe.inference(noise.to(DEV), ["p"], return_latents=True)[1]
+    torch.cuda.synchronize()
+    assert not q
+    ref_noise = rel(T(G["lat_bf16"]), T(G["lat_f32"]))      # the reference's own bf16 path vs its fp32 math: 8.6e-3
+    d = rel(lat, T(G["lat_f32"]))
+    assert d < 2e-2, (d, ref_noise)
+    assert rel(lat, T(G["lat_bf16"])) < 2e-2
+    # the cache both chunks left behind (every 8th row of one head of the first / last layer)
+    assert rel(pipe.kv_cache1[0]["k"][0, :3120:8, 3], T(G["k0_head3_f32"])) < 2e-2
+    assert rel(pipe.kv_cache1[29]["v"][0, :3120:8, 7], T(G["v29_head7_f32"])) < 2e-2

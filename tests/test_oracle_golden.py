@@ -210,3 +210,23 @@ def test_rollout(weights, name, tag):
     # bf16-vs-fp32 distance at this shape is 3.5e-3
     tol = 5e-5 if tag == "f32" else 1.5e-2
     assert rel(lat.float(), T(R[f"{name}_lat_{tag}"])) < tol
+
+
+# ------------------------------------------------------------------------------- BASELINE configs[0] at full shape
+def test_tconfig_full_shape_rollout_oracle_vs_reference():
+    """The oracle's float32 rollout of the T config at the FULL Wan-1.3B shape (2 chunks x 5 forwards of 1560 tokens,
+    ~1.5 minutes on 8 cores) against the latents the reference itself produced (oracle/make_golden.py --only tconfig)."""
+    G = load("tconfig_1p3b.npz")
+    g = torch.Generator().manual_seed(int(G["input_seed"]))
+    bf = lambda shape: torch.randn(shape, generator=g).to(torch.bfloat16)  # noqa: E731
+    noise = bf((1, 2, 16, 60, 104))
+    pe = bf((1, 512, sfa.WAN_1_3B.text_dim))
+    pe[:, 93:] = 0
+    eps = [bf((1, 16, 60, 104)) for _ in range(6)]
+    assert noise.double().sum().item() == float(G["noise_checksum"]), "torch CPU generator stream changed; regenerate the fixture"
+    W = wo.prepare_weights(sfa.synth_state_dict(sfa.WAN_1_3B, seed=0), torch.float32)
+    cfg = cfg_of(sfa.WAN_1_3B)
+    args = wo.RolloutArgs(num_frame_per_block=1, independent_first_frame=True, timestep_shift=8.0)
+    with torch.no_grad():
+        lat = wo.rollout(W, cfg, args, noise.float(), pe.float(), [e.float() for e in eps], cache_tokens=2 * 1560)
+    assert rel(lat, T(G["lat_f32"])) < 2e-5
