@@ -432,6 +432,60 @@ def gen_tconfig(ns):
     print("tconfig_1p3b.npz", len(out), "arrays")
 
 
+def gen_s1(ns):
+    """BASELINE configs[1] ("S1"), first two chunks at the FULL Wan-1.3B shape: self_forcing_dmd settings
+    (steps [1000, 750, 500, 250] warped with shift 5.0, 3 frames per block, context_noise 0), noise
+    [1, 6, 16, 60, 104] => 2 chunks x (4 + 1) forwards of 4680 tokens against caches of 4680 / 9360 tokens -- the shapes
+    at which the rollout's large-tile kernels run.  fp32 math variant of the reference (and its bf16 run for the
+    distance between the two).  Stored: latent frames 0, 2, 3 and 5 in full, per-frame sums of all six."""
+    import time
+    shape = sfa.WAN_1_3B
+    sd = sfa.synth_state_dict(shape, seed=0)
+    H, W = 60, 104
+    fs = (H // 2) * (W // 2)
+    g = torch.Generator().manual_seed(5151)
+    noise = bf16_randn((1, 6, 16, H, W), g)
+    pe = bf16_randn((1, 512, shape.text_dim), g)
+    pe[:, 141:] = 0
+    eps = [bf16_randn((3, 16, H, W), g) for _ in range(6)]
+    out = {"weights_seed": np.array(0), "input_seed": np.array(5151), "noise_checksum": np.array(noise.double().sum().item()),
+           "pe_checksum": np.array(pe.double().sum().item()), "eps_checksum": np.array(sum(e.double().sum().item() for e in eps))}
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                                 independent_first_frame=False, num_frame_per_block=3, context_noise=0, model_kwargs={})
+    lats = {}
+    for tag, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        t0 = time.time()
+        model = build_model(ns, shape, sd, dtype)
+        wrapper = ref_shim.build_wrapper(ns, model, 5.0)
+        sink_out = io.StringIO()
+        with contextlib.redirect_stdout(sink_out):
+            pipe = ns.CausalInferencePipeline(args, device="cpu", generator=wrapper,
+                                              text_encoder=lambda text_prompts: {"prompt_embeds": pe.to(dtype)},
+                                              vae=_IdentityVAE())
+        pipe.kv_cache1, pipe.crossattn_cache = fresh_caches(shape, 1, 6 * fs, dtype)
+        queue = list(eps)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, *a, **kw: queue.pop(0).to(t.dtype).reshape(t.shape)
+        try:
+            with contextlib.redirect_stdout(sink_out), torch.no_grad():
+                _, lat = pipe.inference(noise.to(dtype), ["p"], return_latents=True)
+        finally:
+            torch.randn_like = orig
+        assert not queue
+        lats[tag] = lat.float()
+        print("s1", tag, "latents rms %.4f" % lat.float().pow(2).mean().sqrt().item(), "%.0f s" % (time.time() - t0), flush=True)
+        del model, wrapper, pipe
+    lf = lats["f32"]
+    out["frames"] = np.array([0, 2, 3, 5])
+    out["lat_f32_frames"] = f32(lf[:, [0, 2, 3, 5]])
+    out["lat_f32_frame_sums"] = lf.double().sum(dim=(0, 2, 3, 4)).numpy()
+    out["lat_f32_frame_abs_sums"] = lf.double().abs().sum(dim=(0, 2, 3, 4)).numpy()
+    out["ref_bf16_vs_f32"] = np.array(((lats["bf16"] - lf).norm() / lf.norm()).item())
+    print("s1: reference bf16 vs fp32 rel err %.4f" % float(out["ref_bf16_vs_f32"]))
+    np.savez_compressed(os.path.join(GOLD, "s1_2chunks_1p3b.npz"), **out)
+    print("s1_2chunks_1p3b.npz", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -452,6 +506,8 @@ def main():
             gen_full(ns)
         if "tconfig" in todo:
             gen_tconfig(ns)
+        if "s1" in todo:
+            gen_s1(ns)
 
 
 if __name__ == "__main__":

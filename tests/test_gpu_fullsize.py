@@ -201,3 +201,35 @@ def test_tconfig_rollout_vs_reference_golden(sd_1p3b):
     # the cache both chunks left behind (every 8th row of one head of the first / last layer)
     assert rel(pipe.kv_cache1[0]["k"][0, :3120:8, 3], T(G["k0_head3_f32"])) < 2e-2
     assert rel(pipe.kv_cache1[29]["v"][0, :3120:8, 7], T(G["v29_head7_f32"])) < 2e-2
+
+
+def test_s1_first_two_chunks_vs_reference_golden(sd_1p3b):
+    """BASELINE configs[1] (the benchmark's own configuration), first two chunks at the FULL Wan-1.3B shape: 10 forwards
+    of 4680 tokens against caches of 4680 / 9360 tokens -- where the 64-row attention kernel and the large-tile GEMM
+    run -- against the latents the reference's own pipeline produced in fp32 (oracle/make_golden.py --only s1)."""
+    import numpy as np
+    G = np.load(os.path.join(ROOT, "tests", "golden", "s1_2chunks_1p3b.npz"))
+    g = torch.Generator().manual_seed(int(G["input_seed"]))
+    bf = lambda shape: torch.randn(shape, generator=g).to(torch.bfloat16)  # noqa: E731
+    noise = bf((1, 6, 16, 60, 104))
+    pe = bf((1, 512, sfa.WAN_1_3B.text_dim))
+    pe[:, 141:] = 0
+    eps = [bf((3, 16, 60, 104)) for _ in range(6)]
+    assert noise.double().sum().item() == float(G["noise_checksum"]) and pe.double().sum().item() == float(G["pe_checksum"]) \
+        and sum(e.double().sum().item() for e in eps) == float(G["eps_checksum"]), \
+        "torch CPU generator stream changed; regenerate the fixture"
+    lat, pipe = _rollout(sd_1p3b, 6, 3, -1, noise, eps, pe)
+    torch.cuda.synchronize()
+    frames = [int(f) for f in G["frames"]]
+    want = torch.from_numpy(G["lat_f32_frames"])
+    d = rel(lat[:, frames], want)
+    assert d < 2e-2, (d, float(G["ref_bf16_vs_f32"]))
+    for j, f in enumerate(frames):     # and frame by frame
+        assert rel(lat[:, f], want[:, j]) < 2e-2, f
+    # all six frames through their sums and absolute sums (a systematic bias or gain error would show here)
+    sums = lat.double().sum(dim=(0, 2, 3, 4)).cpu().numpy()
+    abs_sums = lat.double().abs().sum(dim=(0, 2, 3, 4)).cpu().numpy()
+    # measured: 7.5e-3 on the stored frames (the reference's own bf16 run: 7.8e-3), sums within 2.6e-4 / 2.4e-4
+    assert np.all(np.abs(sums - G["lat_f32_frame_sums"]) < 1e-3 * G["lat_f32_frame_abs_sums"])
+    assert np.all(np.abs(abs_sums - G["lat_f32_frame_abs_sums"]) < 1e-3 * G["lat_f32_frame_abs_sums"])
+    assert int(pipe.kv_cache1[0]["local_end_index"]) == 6 * 1560
