@@ -59,6 +59,37 @@ def main():
     print(f"t5_reduced: context {out['context_f32'].shape}, rms {out['context_f32'].std():.3f}, reference bf16-vs-fp32 rel err {noise:.4f}")
     np.savez_compressed(os.path.join(OUT, "t5_reduced.npz"), ids=ids.numpy(), mask=mask.numpy(), seed=np.int64(seed),
                         ref_bf16_rel_err=np.float64(noise), **out)
+    xxl_geometry()
+
+
+def xxl_geometry():
+    """umT5-XXL LAYER geometry (dim 4096, 64 heads of 64, gated-GELU ffn 10240) with 2 layers and a 512-row vocabulary:
+    every kernel of the encoder at its real channel counts.  ids [2, 192] with lengths 192 and 45.  Stored: every 4th
+    row x every 4th channel of the fp32 output, its full-tensor sum / abs-sum per prompt, and the reference's own
+    bf16-vs-fp32 distance."""
+    shape, seed = tw.T5Shape(vocab_size=512, num_layers=2), 3
+    sd = tw.synth_t5_state_dict(shape, seed=seed)
+    g = torch.Generator().manual_seed(11)
+    L, lens = 192, [192, 45]
+    ids = torch.randint(1, shape.vocab_size, (len(lens), L), generator=g)
+    mask = torch.zeros(len(lens), L, dtype=torch.long)
+    for i, n in enumerate(lens):
+        mask[i, :n] = 1
+        ids[i, n:] = 0
+    res = {}
+    for dtype, tag in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        m = build_reference(shape, sd, dtype)
+        with torch.no_grad():
+            ctx = m(ids, mask)
+        for u, n in zip(ctx, mask.gt(0).sum(dim=1).long()):
+            u[n:] = 0.0
+        res[tag] = ctx.float()
+    f = res["f32"]
+    noise = ((res["bf16"] - f).norm() / f.norm()).item()
+    print(f"t5_xxl_geometry: context {tuple(f.shape)}, rms {f.std():.3f}, reference bf16-vs-fp32 rel err {noise:.4f}")
+    np.savez_compressed(os.path.join(OUT, "t5_xxl_geometry.npz"), ids=ids.numpy(), mask=mask.numpy(), seed=np.int64(seed),
+                        context_f32_sub=f[:, ::4, ::4].numpy(), sums=f.double().sum(dim=(1, 2)).numpy(),
+                        abs_sums=f.double().abs().sum(dim=(1, 2)).numpy(), ref_bf16_rel_err=np.float64(noise))
 
 
 if __name__ == "__main__":

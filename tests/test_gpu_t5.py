@@ -98,3 +98,20 @@ def test_pipeline_with_real_text_encoder(tmp_path):
     noise = torch.randn(1, 2, 16, 8, 12, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(DEV)
     _, lat = pipe.inference(noise, ["a red fox"], return_latents=True)
     assert lat.shape == (1, 2, 16, 8, 12) and torch.isfinite(lat.float()).all()
+
+
+def test_encoder_at_xxl_layer_geometry_vs_reference_golden():
+    """Every encoder kernel at umT5-XXL's real channel counts (dim 4096, 64 heads of 64, ffn 10240; 2 layers) against
+    the reference's fp32 run (oracle/make_golden_t5.py::xxl_geometry), prompts of 192 and 45 tokens."""
+    g = np.load(os.path.join(GOLD, "t5_xxl_geometry.npz"))
+    shape = tw.T5Shape(vocab_size=512, num_layers=2)
+    enc = sfa.WanTextEncoder(tw.synth_t5_state_dict(shape, seed=int(g["seed"])), device=DEV, shape=shape)
+    out = enc.encode_ids(torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"]))["prompt_embeds"]
+    gold = torch.from_numpy(g["context_f32_sub"])
+    err = rel(out[:, ::4, ::4].float(), gold)
+    assert err < TOL, f"rel err {err:.4f} (reference bf16 itself: {float(g['ref_bf16_rel_err']):.4f})"
+    for i, n in enumerate(g["mask"].sum(1)):
+        if n < out.shape[1]:
+            assert float(out[i, n:].float().abs().max()) == 0.0
+    sums = out.double().sum(dim=(1, 2)).cpu().numpy()
+    assert np.all(np.abs(sums - g["sums"]) < 2e-3 * g["abs_sums"])

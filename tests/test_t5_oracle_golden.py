@@ -51,3 +51,15 @@ def test_t5_param_shapes():
     ps = tw.t5_param_shapes(tw.UMT5_XXL)
     assert len(ps) == 2 + 24 * 10 and ps["blocks.23.pos_embedding.embedding.weight"] == (32, 64)
     assert sum(int(np.prod(v)) for v in ps.values()) > 5.6e9
+
+
+def test_encoder_fp32_matches_reference_at_xxl_layer_geometry():
+    """dim 4096, 64 heads, gated-GELU ffn 10240 (2 layers, 512-row vocabulary): oracle/make_golden_t5.py::xxl_geometry."""
+    g = np.load(os.path.join(GOLD, "t5_xxl_geometry.npz"))
+    s = tw.T5Shape(vocab_size=512, num_layers=2)
+    cfg = to.T5OracleConfig(dim=s.dim, dim_attn=s.dim_attn, dim_ffn=s.dim_ffn, num_heads=s.num_heads, num_layers=s.num_layers,
+                            num_buckets=s.num_buckets)
+    sd = tw.synth_t5_state_dict(s, seed=int(g["seed"]))
+    out = to.text_encoder_forward(cfg, to.prepare_weights(sd, torch.float32), torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"]))
+    assert rel(out[:, ::4, ::4].numpy(), g["context_f32_sub"]) < 1e-5
+    assert np.allclose(out.double().sum(dim=(1, 2)).numpy(), g["sums"], rtol=0, atol=1e-4 * g["abs_sums"].max())
