@@ -11,7 +11,9 @@ TEST INFRASTRUCTURE.  Imports `wan/utils/fm_solvers_unipc.py` and `pipeline/caus
                                      (seeded weights of self_forcing_amd.synth_state_dict, two text conditions),
                                      latents in float32 and in the reference's own bf16
 
-Usage: python oracle/make_golden_unipc.py
+    tests/golden/unipc_full_1p3b.npz (--full)  the same pipeline at the FULL Wan-1.3B shape: one 1-frame chunk, 4 steps
+
+Usage: python oracle/make_golden_unipc.py [--full]
 """
 from __future__ import annotations
 
@@ -141,11 +143,56 @@ def gen_rollouts(ns):
     print("unipc_rollouts.npz", len(out), "arrays")
 
 
+def gen_full_shape(ns):
+    """The CFG sampler at the FULL Wan-1.3B shape: one 1-frame chunk (1560 tokens), 4 UniPC steps, guidance 3, shift 5:
+    2 x 4 + 2 forwards of the reference's CausalDiffusionInferencePipeline, fp32 math variant and bf16 as shipped."""
+    import time
+    shape = sfa.WAN_1_3B
+    sd = sfa.synth_state_dict(shape, seed=0)
+    H, W = 60, 104
+    fs = (H // 2) * (W // 2)
+    g = torch.Generator().manual_seed(6161)
+    noise = bf16_randn((1, 1, 16, H, W), g)
+    pe = bf16_randn((1, 512, shape.text_dim), g)
+    pe[:, 88:] = 0
+    ne = bf16_randn((1, 512, shape.text_dim), g)
+    ne[:, 12:] = 0
+    out = {"weights_seed": np.array(0), "input_seed": np.array(6161), "noise_checksum": np.array(noise.double().sum().item()),
+           "pe_checksum": np.array(pe.double().sum().item()), "ne_checksum": np.array(ne.double().sum().item())}
+    args = types.SimpleNamespace(num_train_timestep=1000, timestep_shift=5.0, independent_first_frame=False,
+                                 num_frame_per_block=1, negative_prompt="NEG", guidance_scale=3.0, model_kwargs={})
+    for tag, dtype in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+        t0 = time.time()
+        model = build_model(ns, shape, sd, dtype)
+        wrapper = ref_shim.build_wrapper(ns, model, 5.0)
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            pipe = ns.CausalDiffusionInferencePipeline(
+                args, device="cpu", generator=wrapper, vae=_IdentityVAE(), image_encoder=object(),
+                text_encoder=lambda text_prompts: {"prompt_embeds": (ne if text_prompts[0] == "NEG" else pe).to(dtype)})
+        pipe.sampling_steps = 4
+        pipe.kv_cache_pos, pipe.crossattn_cache_pos = fresh_caches(shape, 1, fs, dtype)
+        pipe.kv_cache_neg, pipe.crossattn_cache_neg = fresh_caches(shape, 1, fs, dtype)
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink), torch.no_grad():
+            _, lat = pipe.inference(noise.to(dtype), ["p"], None, None, None, return_latents=True)
+        out[f"lat_{tag}"] = f32(lat)
+        print("cfg full shape", tag, "latents rms %.4f" % lat.float().pow(2).mean().sqrt().item(), "%.0f s" % (time.time() - t0), flush=True)
+        del model, wrapper, pipe
+    d = np.linalg.norm(out["lat_bf16"] - out["lat_f32"]) / np.linalg.norm(out["lat_f32"])
+    out["ref_bf16_vs_f32"] = np.array(d)
+    del out["lat_bf16"]
+    print("cfg full shape: reference bf16 vs fp32 rel err %.4f" % d)
+    np.savez_compressed(os.path.join(OUT, "unipc_full_1p3b.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ns = ref_shim.load_sampler()
     with torch.no_grad():
+        if "--full" in sys.argv:          # ~4 minutes of CPU time
+            gen_full_shape(ns)
+            return
         gen_steps(ns)
         gen_rollouts(ns)
 

@@ -232,3 +232,30 @@ def test_cfg_rollout_batch2_matches_per_sample(sd_reduced):
     both = run([0, 1])
     for i in range(2):
         assert rel(both[i:i + 1], run([i])) < 1e-6
+
+
+def test_cfg_sampler_full_1p3b_shape_vs_reference_golden():
+    """The reference's CausalDiffusionInferencePipeline at the FULL Wan-1.3B shape (one 1-frame chunk of 1560 tokens,
+    4 UniPC steps, guidance 3: 2 x 4 + 2 forwards; oracle/make_golden_unipc.py --full) against the HIP path."""
+    G = np.load(os.path.join(GOLD, "unipc_full_1p3b.npz"))
+    shape = sfa.WAN_1_3B
+    g = torch.Generator().manual_seed(int(G["input_seed"]))
+    bf = lambda sh: torch.randn(sh, generator=g).to(torch.bfloat16)  # noqa: E731
+    noise = bf((1, 1, 16, 60, 104))
+    pe = bf((1, 512, shape.text_dim))
+    pe[:, 88:] = 0
+    ne = bf((1, 512, shape.text_dim))
+    ne[:, 12:] = 0
+    assert noise.double().sum().item() == float(G["noise_checksum"]) and pe.double().sum().item() == float(G["pe_checksum"]) \
+        and ne.double().sum().item() == float(G["ne_checksum"]), "torch CPU generator stream changed; regenerate the fixture"
+    args = SimpleNamespace(num_train_timestep=1000, timestep_shift=5.0, independent_first_frame=False,
+                           num_frame_per_block=1, negative_prompt="NEG", guidance_scale=3.0)
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sfa.synth_state_dict(shape, seed=0), timestep_shift=5.0,
+                                  is_causal=True, device=DEV)
+    pipe = sfa.CausalDiffusionInferencePipeline(args, DEV, generator=gen, text_encoder=TwoPromptEncoder(pe.to(DEV), ne.to(DEV)),
+                                                vae=sfa.IdentityVAE())
+    pipe.sampling_steps = 4
+    lat = pipe.inference(noise.to(DEV), ["p"], None, None, None, return_latents=True)[1]
+    ref_noise = float(G["ref_bf16_vs_f32"])
+    d = rel(lat, T(G["lat_f32"]))
+    assert d < max(2e-2, 1.5 * ref_noise), (d, ref_noise)
