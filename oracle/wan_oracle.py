@@ -24,7 +24,7 @@ Two numeric modes, selected by the dtype of the prepared weights:
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch

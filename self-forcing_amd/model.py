@@ -9,7 +9,6 @@ Linears), the fp32 RoPE tables and a per-shape workspace; `forward` is ONE C cal
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Dict, List, Optional
 
 import torch

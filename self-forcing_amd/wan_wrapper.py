@@ -25,7 +25,6 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib
 from .kvcache import plan_cache_update
 from .model import CausalWanModel
 from .scheduler import FlowMatchScheduler
