@@ -197,23 +197,37 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
     // instruction (32-byte partial lines): a quarter of HBM's write efficiency on the 300 MB volumes.
     constexpr int RBP = 64 * NT + 16;    // padded row bytes
     char* obuf = smem;                   // (the k-loop's last __syncthreads has released the stages)
+    // bias and residual are requested for the whole wave tile first and consumed afterwards (one memory round trip
+    // instead of 4 NT dependent ones, see gemm_epilogue_lds)
+    int ncol[NT];
+    bf16x4 bias_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      ncol[nt] = min(n0 + wc * (16 * NT) + nt * 16 + (lane >> 4) * 4, p.Cout - 4);
+      bias_v[nt] = *reinterpret_cast<const bf16x4*>(p.bias + ncol[nt]);
+    }
+    bf16x4 rv[4][NT];
+    if (EPI == SF_CONV_BIAS_RESID) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = min(m0 + wr * 64 + mt * 16 + (lane & 15), p.M - 1);
+        const long grow = (long)p.out_frame0 * p.HW + m;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rv[mt][nt] = *reinterpret_cast<const bf16x4*>(p.resid + grow * p.ldr + ncol[nt]);
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int row = wr * 64 + mt * 16 + (lane & 15);
-      const int m = min(m0 + row, p.M - 1);
-      const long grow = (long)p.out_frame0 * p.HW + m;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = wc * (16 * NT) + nt * 16 + (lane >> 4) * 4;
-        const int n = min(n0 + col, p.Cout - 4);
         float y[4];
-        const bf16x4 b = *reinterpret_cast<const bf16x4*>(p.bias + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j] + (float)b[j];
+        for (int j = 0; j < 4; ++j) y[j] = acc[mt][nt][j] + (float)bias_v[nt][j];
         if (EPI == SF_CONV_BIAS_RESID) {
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.resid + grow * p.ldr + n);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
+          for (int j = 0; j < 4; ++j) y[j] += (float)rv[mt][nt][j];
         }
         bf16x4 o;
 #pragma unroll

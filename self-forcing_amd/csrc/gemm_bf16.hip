@@ -102,27 +102,85 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
   }
 }
 
+// Epilogue arithmetic on operands that are already in registers (see gemm_epilogue_lds).
+template <int EPI>
+__device__ __forceinline__ bf16x4 epi_math(const f32x4& a4, const bf16x4& b, const bf16x4& gm, const bf16x4& ge, const bf16x4& rv) {
+  float y[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[j] = a4[j] + (float)b[j];
+  if (EPI == SF_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+  }
+  if (EPI == SF_EPI_BIAS_GATE_RESID) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] *= (float)(bf16_t)((float)gm[j] + (float)ge[j]);
+  }
+  if (EPI == SF_EPI_BIAS_RESID || EPI == SF_EPI_BIAS_GATE_RESID) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] += (float)rv[j];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16_t)y[j];
+  return o;
+}
+
 // Epilogue through LDS: the wave's (16 MT) x 64 sub-tile is written to its own LDS region as bf16 rows of
 // 128 B (16-byte chunk c of row r at c ^ (r & 7): 2-way conflicts at most on the 8-byte writes, none on the
 // reads) and read back row-wise, so that every global store instruction covers 8 whole 128-byte rows.
 // The direct form writes 32-byte pieces of 16 different rows per instruction: for the 84 MB ffn.0 output
 // that is a quarter of HBM's write efficiency and cost 12-20 us per 256 x 256 tile.
+// All global operands of the epilogue (bias and gate vectors once per column block, residual and per-group gate
+// rows for four row blocks at a time) are REQUESTED FIRST and consumed afterwards: written piece by piece
+// (load bias, wait, load residual, wait, compute, 16-32 times per lane) the epilogue was a chain of dependent memory
+// round trips -- 8 us of a 36 us o-projection, 15 us per 256 x 256 tile.
 template <int EPI, int MT>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x4 (&acc)[MT][4], int m_base, int n_base, char* wbuf, int lane) {
   const int r16 = lane & 15, cg = lane >> 4;
+  constexpr bool GATE = EPI == SF_EPI_BIAS_GATE_RESID;
+  constexpr bool RESID = EPI == SF_EPI_BIAS_RESID || EPI == SF_EPI_BIAS_GATE_RESID;
+  const bf16x4 zero4 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+  int ncol[4];
+  bf16x4 bias_v[4], gm_v[4];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = mt * 16 + r16;
-    const int m = min(m_base + row, p.M - 1);
-    const bf16_t* e0row = nullptr;
-    if (EPI == SF_EPI_BIAS_GATE_RESID) e0row = p.gate_e0 + (long)(m / p.rows_per_group) * p.gate_group_stride;
+  for (int nt = 0; nt < 4; ++nt) {
+    ncol[nt] = min(n_base + nt * 16 + cg * 4, p.N - 4);
+    bias_v[nt] = zero4;
+    gm_v[nt] = zero4;
+  }
+  if (p.bias) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int col = nt * 16 + cg * 4;                       // 0..63 within the wave's columns
-      const int n = min(n_base + col, p.N - 4);
-      const bf16x4 o = epi_apply<EPI>(p, acc[mt][nt], m, n, e0row);
-      const int chunk = (col >> 3) ^ (row & 7);
-      *reinterpret_cast<bf16x4*>(wbuf + row * 128 + (chunk << 4) + (col & 4) * 2) = o;
+    for (int nt = 0; nt < 4; ++nt) bias_v[nt] = *reinterpret_cast<const bf16x4*>(p.bias + ncol[nt]);
+  }
+  if (GATE) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) gm_v[nt] = *reinterpret_cast<const bf16x4*>(p.gate_mod + ncol[nt]);
+  }
+  constexpr int MB = 4;                                      // row blocks whose operands are in flight together
+#pragma unroll
+  for (int m0 = 0; m0 < MT; m0 += MB) {
+    bf16x4 rv[MB][4], ge[MB][4];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int m = min(m_base + (m0 + i) * 16 + r16, p.M - 1);
+      const bf16_t* e0row = GATE ? p.gate_e0 + (long)(m / p.rows_per_group) * p.gate_group_stride : nullptr;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        rv[i][nt] = RESID ? *reinterpret_cast<const bf16x4*>(p.resid + (long)m * p.ldr + ncol[nt]) : zero4;
+        ge[i][nt] = GATE ? *reinterpret_cast<const bf16x4*>(e0row + ncol[nt]) : zero4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int row = (m0 + i) * 16 + r16;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = nt * 16 + cg * 4;                     // 0..63 within the wave's columns
+        const bf16x4 o = epi_math<EPI>(acc[m0 + i][nt], bias_v[nt], gm_v[nt], ge[i][nt], rv[i][nt]);
+        const int chunk = (col >> 3) ^ (row & 7);
+        *reinterpret_cast<bf16x4*>(wbuf + row * 128 + (chunk << 4) + (col & 4) * 2) = o;
+      }
     }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes (the region is private to the wave)
