@@ -12,8 +12,8 @@
 // i.e. a GEMM with M = Tout*H*W output positions, N = Cout, K = taps*Cin whose A operand is GATHERED:
 // K is walked in 32-channel slices (Cin % 32 == 0), two slices per 64-deep k-step, every slice lies
 // inside one tap, and a lane's 16-byte piece of an A row comes from the tap-shifted position or -- for
-// the zero padding in h/w, rows past M and the padding slice of an odd slice count -- from a page of
-// zeros.  Causality costs nothing here: the input volume holds the two history frames physically in
+// the zero padding in h/w, rows past M and the padding slice of an odd slice count -- from an offset past the
+// end of the volume, which the range-checked LDS-DMA (buffer_load ... lds) turns into zeros.  Causality costs nothing here: the input volume holds the two history frames physically in
 // front of the new ones (the caller keeps them there), so t + dt never leaves the buffer.
 //
 // Everything after the gather is the GEMM of gemm_bf16.hip: 128 x (32 NT) output tile per 256-thread
@@ -31,8 +31,6 @@ constexpr int CBM = 128, CBK = 64;
 constexpr int CONV_THREADS = 256;
 constexpr int A_TILE_BYTES = CBM * CBK * 2;   // 16 KiB
 
-__device__ __attribute__((aligned(256))) unsigned char sf_zero_page[256];   // zero-initialised
-
 struct ConvP {
   const bf16_t* x;
   const bf16_t* w;
@@ -45,6 +43,7 @@ struct ConvP {
   int Cin, Cout, cpt, ntaps, khw, kw, ph, pw;
   int t_off, nk, ldw, ldo, ldr, out_frame0, inter_c, Tout;
   int tiles_m, tiles_n;
+  unsigned x_bytes;   // size of the input volume the gather may touch (range check of the LDS-DMA)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -72,24 +71,35 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
   const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
   const int m0 = tm * CBM, n0 = tn * BN;
 
-  // ---- the four A pieces of this lane: row r, 16-byte chunk c (which fixes slice half and channel offset)
-  int pt[4], phh[4], pww[4], pcoff[4];
-  bool pvalid[4], phalf[4];
+  // ---- the four A pieces of this lane: row r of the tile, 16-byte chunk c of the 128-byte LDS row (chunks 0-3 hold
+  // the first 32-channel slice of the k-step, 4-7 the second).  Everything that does not depend on the tap is
+  // computed ONCE: the byte offset of the piece at tap (0, 0, 0) and a 9-bit mask of the spatial taps that fall
+  // inside the image.  Per k-step a piece then costs a handful of VALU instructions: offset = base + D(slice) with D
+  // wave-uniform, validity = one bit of the mask, and an invalid piece (zero padding, rows past M, the padding slice
+  // of an odd slice count) gets an out-of-range offset: the range-checked buffer load writes zeros to LDS.
+  unsigned abase[4], vmask[4], parh[4], parw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (wave * 4 + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int m = m0 + r;
-    pvalid[i] = m < p.M;
+    const bool valid = m < p.M;
     const int mm = min(m, p.M - 1);
     const int t = mm / p.HW, hw = mm - t * p.HW;
     const int h = hw / p.W;
-    pt[i] = t + p.t_off;
-    phh[i] = h - p.ph;
-    pww[i] = hw - h * p.W - p.pw;
-    phalf[i] = (c >> 2) != 0;
-    pcoff[i] = (c & 3) * 8;
+    const int hh0 = h - p.ph, ww0 = hw - h * p.W - p.pw;
+    abase[i] = (unsigned)(((((long)(t + p.t_off) * p.Hin + (hh0 >> p.up)) * p.Win + (ww0 >> p.up)) * p.Cin + (c & 3) * 8) * 2);
+    unsigned vm = 0;
+    const int kk = p.khw == 9 ? 3 : 1;
+    for (int dh = 0; dh < kk; ++dh)
+      for (int dw = 0; dw < kk; ++dw)
+        if (valid && (unsigned)(hh0 + dh) < (unsigned)p.H && (unsigned)(ww0 + dw) < (unsigned)p.W) vm |= 1u << (dh * 3 + dw);
+    vmask[i] = vm;
+    parh[i] = (unsigned)hh0 & 1u;
+    parw[i] = (unsigned)ww0 & 1u;
   }
+  // piece i lies in slice ((lane >> 2) & 1) ^ (i & 1) of the k-step (from the chunk swizzle above)
+  const bool lane_hi = ((lane >> 2) & 1) != 0;
   const bf16_t* w_src[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -98,38 +108,59 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
     const int n = min(n0 + r, p.Cout - 1);
     w_src[j] = p.w + (long)n * p.ldw + c * 8;
   }
+  // range-checked view of the input volume (offsets past x_bytes read as zero)
+  u32x4 x_srd;
+  {
+    const unsigned long long a64 = (unsigned long long)p.x;
+    x_srd[0] = __builtin_amdgcn_readfirstlane((unsigned)a64);
+    x_srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(a64 >> 32) & 0xFFFFu);
+    x_srd[2] = __builtin_amdgcn_readfirstlane(p.x_bytes);
+    x_srd[3] = 0x00020000u;
+  }
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  auto dma_a = [&](unsigned voff, unsigned lds_addr) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(x_srd) : "memory");
+  };
 
   // slice cursor of the NEXT stage to issue: slice 2 kt = (tap, cc), cc counting 32-channel groups
   int tap = 0, cc = 0;
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * STAGE + wave * 4096;
+  const unsigned rowB = (unsigned)(p.Win * p.Cin * 2), colB = (unsigned)(p.Cin * 2), frameB = (unsigned)(p.Hin * p.Win * p.Cin * 2);
+  // byte offsets of this lane's four A pieces of the stage the cursor points at; advances the cursor
+  auto gather_offsets = [&](unsigned (&voff)[4]) __attribute__((always_inline)) {
     int tap1 = tap, cc1 = cc + 1;
     if (cc1 >= p.cpt) { cc1 -= p.cpt; ++tap1; }
-    // tap -> (dt, dh, dw): khw is 9 or 1, kw 3 or 1
-    int dt0, dh0, dw0, dt1, dh1, dw1;
+    int dt0, dh0, dw0, dt1, dh1, dw1;   // tap -> (dt, dh, dw): khw is 9 or 1, kw 3 or 1
     if (p.khw == 9) {
       dt0 = (tap * 57) >> 9; const int r0 = tap - 9 * dt0; dh0 = (r0 * 11) >> 5; dw0 = r0 - 3 * dh0;
       dt1 = (tap1 * 57) >> 9; const int r1 = tap1 - 9 * dt1; dh1 = (r1 * 11) >> 5; dw1 = r1 - 3 * dh1;
     } else {
       dt0 = tap; dh0 = dw0 = 0; dt1 = tap1; dh1 = dw1 = 0;
     }
-    const bool ok0 = tap < p.ntaps, ok1 = tap1 < p.ntaps;
+    const unsigned sh0 = tap < p.ntaps ? (unsigned)(dh0 * 3 + dw0) : 31u, sh1 = tap1 < p.ntaps ? (unsigned)(dh1 * 3 + dw1) : 31u;
+    const unsigned base0 = (unsigned)dt0 * frameB + (unsigned)cc * 64u, base1 = (unsigned)dt1 * frameB + (unsigned)cc1 * 64u;
+    // the lane's two slices: pieces 0, 2 use slice `lane_hi`, pieces 1, 3 the other one
+    const unsigned shA = lane_hi ? sh1 : sh0, shB = lane_hi ? sh0 : sh1;
+    if (p.up == 0) {
+      const unsigned d0 = base0 + (unsigned)dh0 * rowB + (unsigned)dw0 * colB, d1 = base1 + (unsigned)dh1 * rowB + (unsigned)dw1 * colB;
+      const unsigned dA = lane_hi ? d1 : d0, dB = lane_hi ? d0 : d1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int dt = phalf[i] ? dt1 : dt0, dh = phalf[i] ? dh1 : dh0, dw = phalf[i] ? dw1 : dw0;
-      const int ch = (phalf[i] ? cc1 : cc) * 32 + pcoff[i];
-      const int hh = phh[i] + dh, ww = pww[i] + dw;
-      const bool ok = pvalid[i] && (phalf[i] ? ok1 : ok0) && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
-      const long off = (((long)(pt[i] + dt) * p.Hin + (hh >> p.up)) * p.Win + (ww >> p.up)) * p.Cin + ch;
-      const void* src = ok ? (const void*)(p.x + off) : (const void*)sf_zero_page;
-      glds16(src, base + i * 1024);
+      for (int i = 0; i < 4; ++i) {
+        const unsigned bad = ((vmask[i] >> ((i & 1) ? shB : shA)) & 1u) - 1u;      // 0 if the tap is inside, ~0 if not
+        voff[i] = (abase[i] + ((i & 1) ? dB : dA)) | (bad & 0xFFFFFFF0u);          // (no select: keeps the code branch-free)
+      }
+    } else {   // fused nearest 2x upsample: the input row / column of a tap depends on the parity of the output position
+      const unsigned tA = lane_hi ? base1 : base0, tB = lane_hi ? base0 : base1;
+      const unsigned dhA = lane_hi ? dh1 : dh0, dhB = lane_hi ? dh0 : dh1, dwA = lane_hi ? dw1 : dw0, dwB = lane_hi ? dw0 : dw1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned bad = ((vmask[i] >> ((i & 1) ? shB : shA)) & 1u) - 1u;
+        const unsigned rdh = (((i & 1) ? dhB : dhA) + parh[i]) >> 1, rdw = (((i & 1) ? dwB : dwA) + parw[i]) >> 1;
+        voff[i] = (abase[i] + ((i & 1) ? tB : tA) + rdh * rowB + rdw * colB) | (bad & 0xFFFFFFF0u);
+      }
     }
-    char* wbase = smem + buf * STAGE + A_TILE_BYTES + wave * (NT * 1024);
-    const int k0 = kt * CBK;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) glds16(w_src[j] + k0, wbase + j * 1024);
-    // advance the cursor by two slices
-    cc += 2;
+    cc += 2;                                   // advance the cursor by two slices
     if (cc >= p.cpt) { cc -= p.cpt; ++tap; }
     if (cc >= p.cpt) { cc -= p.cpt; ++tap; }
   };
@@ -149,41 +180,65 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
+  {   // prologue: stage 0
+    unsigned voff[4];
+    gather_offsets(voff);
+    const unsigned abase_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 4096));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_a(voff[i], abase_lds + i * 1024);
+    char* wbase = smem + A_TILE_BYTES + wave * (NT * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) glds16(w_src[j], wbase + j * 1024);
+  }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
 
   for (int kt = 0; kt < p.nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < p.nk) stage(cur ^ 1, kt + 1);
     const char* buf = smem + cur * STAGE;
+    // The k-step as 4 + NT pinned slices of {MFMAs of the first 32-deep sub-step, one fragment read of the second,
+    // ONE LDS-DMA request of the next stage} (see gemm_bf16.hip), then the second sub-step's MFMAs.  The last k-step
+    // re-requests its own W pieces and all-invalid A pieces into the idle buffer so that the body stays branch-free.
+    const bool more = kt + 1 < p.nk;
+    unsigned voff[4];
+    if (more) {
+      gather_offsets(voff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) voff[i] = 0xFFFFFFF0u;
+    }
+    const unsigned abase_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((cur ^ 1) * STAGE + wave * 4096));
+    char* wbase = smem + (cur ^ 1) * STAGE + A_TILE_BYTES + wave * (NT * 1024);
+    const int kn = min(kt + 1, p.nk - 1) * CBK;
     bf16x8 xf0[4], xf1[4], wf0[NT], wf1[NT];
 #pragma unroll
     for (int t = 0; t < 4; ++t) xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff0);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NS = 4 + NT;               // slices
 #pragma unroll
-    for (int t = 0; t < 4; ++t) xf1[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff1);
+    for (int sl = 0; sl < NS; ++sl) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wf1[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff1);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int q = (4 * NT * sl) / NS; q < (4 * NT * (sl + 1)) / NS; ++q) {
+        const int mt = q / NT, nt = q - mt * NT;
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[mt], acc[mt][nt], 0, 0, 0);
+      }
+      if (sl < 4) {
+        xf1[sl] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + sl * 2048 + coff1);
+        dma_a(voff[sl], abase_lds + sl * 1024);
+      } else {
+        wf1[sl - 4] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + (sl - 4) * 2048 + coff1);
+        glds16(w_src[sl - 4] + kn, wbase + (sl - 4) * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
-    // first sub-step's fragments up front, the second sub-step's reads under the first one's MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 + NT, 0);
-#pragma unroll
-    for (int i = 0; i < 4 + NT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, (4 * NT) / (4 + NT) > 0 ? (4 * NT) / (4 + NT) : 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT, 0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // drains the in-flight LDS-DMA (vmcnt(0)) and orders the stage swap
   }
 
@@ -369,6 +424,11 @@ extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
   p.ph = a->kh / 2; p.pw = a->kw / 2;
   p.t_off = a->t_in_offset; p.nk = nk; p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr;
   p.out_frame0 = a->out_frame_offset; p.inter_c = a->interleave_c;
+  {   // frames [0, t_in_offset + Tout + kt - 1) of the input volume can be gathered from
+    const long xb = (long)(a->t_in_offset + a->Tout + a->kt - 1) * a->Hin * a->Win * a->Cin * 2;
+    SF_CHECK(xb < 0xFFFFFF00L, "sf_conv_igemm: input volume of %ld bytes exceeds the 4 GiB the gather's 32-bit offsets cover", xb);
+    p.x_bytes = (unsigned)xb;
+  }
   const int nt = sf_conv_pick_nt(a->Cout);
   p.tiles_m = (p.M + CBM - 1) / CBM;
   p.tiles_n = (a->Cout + 32 * nt - 1) / (32 * nt);
