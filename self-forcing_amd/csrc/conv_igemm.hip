@@ -180,8 +180,8 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  {   // prologue: stage 0
-    unsigned voff[4];
+  unsigned voff[4];                         // offsets of the stage that the NEXT k-step requests
+  {   // prologue: stage 0 requested, the offsets of stage 1 computed
     gather_offsets(voff);
     const unsigned abase_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 4096));
 #pragma unroll
@@ -189,6 +189,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
     char* wbase = smem + A_TILE_BYTES + wave * (NT * 1024);
 #pragma unroll
     for (int j = 0; j < NT; ++j) glds16(w_src[j], wbase + j * 1024);
+    if (p.nk > 1) {
+      gather_offsets(voff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) voff[i] = 0xFFFFFFF0u;
+    }
   }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
@@ -197,16 +203,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
     const int cur = kt & 1;
     const char* buf = smem + cur * STAGE;
     // The k-step as 4 + NT pinned slices of {MFMAs of the first 32-deep sub-step, one fragment read of the second,
-    // ONE LDS-DMA request of the next stage} (see gemm_bf16.hip), then the second sub-step's MFMAs.  The last k-step
-    // re-requests its own W pieces and all-invalid A pieces into the idle buffer so that the body stays branch-free.
-    const bool more = kt + 1 < p.nk;
-    unsigned voff[4];
-    if (more) {
-      gather_offsets(voff);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) voff[i] = 0xFFFFFFF0u;
-    }
+    // ONE LDS-DMA request of the next stage} (see gemm_bf16.hip), then the second sub-step's MFMAs, under which the
+    // gather offsets of the stage after next are computed.  The last k-step re-requests its own W pieces and
+    // all-invalid A pieces into the idle buffer so that the body stays branch-free.
     const unsigned abase_lds = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((cur ^ 1) * STAGE + wave * 4096));
     char* wbase = smem + (cur ^ 1) * STAGE + A_TILE_BYTES + wave * (NT * 1024);
     const int kn = min(kt + 1, p.nk - 1) * CBK;
@@ -232,6 +231,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void conv_igemm_kernel(ConvP p) {
         glds16(w_src[sl - 4] + kn, wbase + (sl - 4) * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kt + 2 < p.nk) {
+      gather_offsets(voff);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) voff[i] = 0xFFFFFFF0u;
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
