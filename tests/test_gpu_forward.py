@@ -327,3 +327,37 @@ def test_add_condition_pose_tokens_vs_oracle():
     with pytest.raises(ValueError, match="spatial dim"):
         gen(x.to(DEV), {"prompt_embeds": pe.to(DEV), "add_condition": cond[:, :-1].to(DEV)}, t.to(DEV), pipe.kv_cache1,
             pipe.crossattn_cache, 0)
+
+
+def test_rollout_bit_reproducible_beside_vae_convolutions(sd_reduced):
+    """The rollout must not depend on what runs on another HIP stream.  It once did: with the VAE's convolution
+    (MFMA + LDS-DMA waves) sharing the CUs, compiler-formed packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32
+    with op_sel) in the q/k RoPE kernel intermittently returned wrong values in lanes 48-63 -- 6 to 15 of 15 rollouts
+    differed, in up to a third of the overlapped streaming runs.  The library is built with -fno-slp-vectorize
+    since (csrc/Makefile); this test is the regression check for it."""
+    from self_forcing_amd.vae import repack_conv
+    g = torch.Generator().manual_seed(41)
+    noise = torch.randn(1, 6, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    eps = [torch.randn(2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(9)]
+    pipe = make_pipe(sd_reduced, 2, False, 5.0, pe=pe)
+    q = []
+    pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+    xc = torch.randn(6, 64, 96, 64, generator=g).to(torch.bfloat16).to(DEV)
+    wc = repack_conv((torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(torch.bfloat16)).to(DEV)
+    bc = torch.randn(64, generator=g).to(torch.bfloat16).to(DEV)
+    side = torch.cuda.Stream(device=DEV)
+
+    def rollout():
+        q.extend(eps)
+        return pipe.inference(noise, ["p"], return_latents=True)[1].clone()
+
+    ref = rollout()
+    torch.cuda.synchronize()
+    for _ in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(200):
+                sfa.ops.conv_igemm(xc, wc, bc, (3, 3, 3), 4)
+        lat = rollout()
+        torch.cuda.synchronize()
+        assert torch.equal(lat, ref)
