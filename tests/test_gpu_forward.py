@@ -361,3 +361,37 @@ def test_rollout_bit_reproducible_beside_vae_convolutions(sd_reduced):
         lat = rollout()
         torch.cuda.synchronize()
         assert torch.equal(lat, ref)
+
+
+def test_two_streams_rollout_plus_decode_match_sequential(sd_reduced):
+    """RolloutPool with the real VAE in every pipeline: while one stream decodes its clip the other one is still
+    denoising (the configuration of bench.py's rollout + decode rate).  Latents and pixels must equal the one-stream
+    run bit for bit, for every job, over several rounds."""
+    from self_forcing_amd import vae_weights as vw
+    shape = sfa.WAN_REDUCED
+    g = torch.Generator().manual_seed(17)
+    jobs = []
+    for j in range(6):
+        noise = torch.randn(1, 4, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16)
+        eps = [torch.randn(2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(6)]
+        jobs.append((f"prompt {j}", noise, eps))
+    args = SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                           independent_first_frame=False, num_frame_per_block=2, context_noise=0)
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd_reduced, timestep_shift=5.0, is_causal=True, device=DEV)
+    enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=DEV)
+    vsd = vw.synth_vae_state_dict(vw.VAE_REDUCED, seed=0)
+    make_vae = lambda: sfa.WanVAEWrapper(vsd, device=DEV, shape=vw.VAE_REDUCED)  # noqa: E731
+
+    def roll(pipe, job):
+        prompt, noise, eps = job
+        q = list(eps)
+        pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+        video, lat = pipe.inference(noise.to(DEV), [prompt], return_latents=True)
+        return lat.clone(), video.clone()
+
+    seq = sfa.RolloutPool(args, DEV, gen, lambda: enc, make_vae, streams=1).run(jobs, roll)
+    pool = sfa.RolloutPool(args, DEV, gen, lambda: enc, make_vae, streams=2)
+    for _ in range(3):
+        par = pool.run(jobs, roll)
+        for (la, va), (lb, vb) in zip(seq, par):
+            assert torch.equal(la, lb) and torch.equal(va, vb)
