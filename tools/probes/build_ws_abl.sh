@@ -11,7 +11,7 @@ mkdir -p "$ROOT/tools/probes/abl"
 while [ $# -ge 2 ]; do
   name=$1; abl=$2; shift 2
   python "$ROOT/tools/gen_attention_ws.py" --abl "$abl" --out /tmp/ws_$name.inc > /dev/null
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize \
      -fno-honor-nans -fno-honor-infinities -DSF_WITH_WS_KERNEL -DSF_WS_INC="\"/tmp/ws_$name.inc\"" -c attention.hip -o /tmp/abl_att_$name.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 gemm_bf16.o /tmp/abl_att_$name.o elementwise.o \
      small_linear.o dit_forward.o conv_igemm.o vae_elementwise.o vae_decode.o t5_encoder.o capi.o -o "$ROOT/tools/probes/abl/libabl_$name.so"
