@@ -26,8 +26,12 @@ A, W_, B_ = bf(4680, 1536), bf(4608, 1536, sc=0.03), bf(4608)
 O_ = torch.empty(4680, 4608, dtype=torch.bfloat16, device=DEV)
 xq, xk = bf(1, 4680, 12, 128), bf(1, 9360, 12, 128)
 side = torch.cuda.Stream(device=DEV)
+w1 = repack_conv((torch.randn(64, 64, 1, 1, 1, generator=g) * 0.05).to(torch.bfloat16)).to(DEV)
+w133 = repack_conv((torch.randn(64, 64, 1, 3, 3, generator=g) * 0.05).to(torch.bfloat16)).to(DEV)
 loads = {
     "nothing": lambda: None,
+    "conv_igemm 1x1x1 (no padding, no out-of-range pieces) x600": lambda: [ops.conv_igemm(xc, w1, bc, (1, 1, 1), 4) for _ in range(600)],
+    "conv_igemm 1x3x3 x400": lambda: [ops.conv_igemm(xc, w133, bc, (1, 3, 3), 4) for _ in range(400)],
     "conv_igemm x300": lambda: [ops.conv_igemm(xc, wc, bc, (3, 3, 3), 4) for _ in range(300)],
     "our gemm x200": lambda: [ops.gemm(A, W_, B_, out=O_) for _ in range(200)],
 }
