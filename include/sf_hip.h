@@ -12,7 +12,8 @@
  *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
  *   - every tensor is bf16 (uint16 storage) unless stated; row-major; strides in ELEMENTS;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream), allocates nothing, never synchronises, keeps no global state;
+ *     stream), allocates nothing, never synchronises, reads no environment variables and keeps no
+ *     state between calls (apart from registering a kernel's LDS size with the runtime on first use);
  *   - return 0 on success, negative on error; `sf_last_error()` gives a thread-local message.
  */
 #ifndef SF_HIP_H
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 4
+#define SF_HIP_ABI_VERSION 5
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -61,7 +62,11 @@ typedef struct sf_gemm_args {
   int32_t batch;       /* > 1: `batch` independent products; entry b uses a + b*a_bstride, w + b*w_bstride,
                           out + b*o_bstride, resid + b*r_bstride (elements; bias / gates shared); 0 or 1: one product */
   int64_t a_bstride, w_bstride, o_bstride, r_bstride;
+  int32_t structure;   /* enum sf_gemm_structure: 0 = picked from the shape; the others force a tiling (tests, A/B timing) */
 } sf_gemm_args;
+
+enum sf_gemm_structure { SF_GEMM_AUTO = 0, SF_GEMM_T128 = 1 /* 128 x 128 tile, 4 waves, 2 workgroups / CU */,
+                         SF_GEMM_T256 = 2 /* 256 x 256 tile, 8 waves, 1 workgroup / CU */ };
 
 int sf_gemm_bf16(const sf_gemm_args* args, void* stream);
 
@@ -119,6 +124,15 @@ int sf_kv_evict(void* cache, int B, int64_t cache_tokens, int row_elems, int sin
 int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
                  int64_t q_stride, int64_t q_bstride, int64_t kv_stride, int64_t kv_bstride,
                  int64_t o_stride, int64_t o_bstride, void* stream);
+
+/* The same with the kernel structure named by the caller instead of picked from the shape (tests and A/B timing;
+ * every structure computes every shape): SF_ATTN_R64 = 64 query rows per wave, one wave per SIMD, hand-scheduled
+ * (256 rows per workgroup); SF_ATTN_W8 = 8-wave anti-phase workgroups of 256 rows; SF_ATTN_W4 = 4-wave workgroups of
+ * 128 rows.  sf_attention == sf_attention_ex(..., SF_ATTN_AUTO, stream). */
+enum sf_attn_structure { SF_ATTN_AUTO = 0, SF_ATTN_R64 = 1, SF_ATTN_W8 = 2, SF_ATTN_W4 = 3 };
+int sf_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
+                    int64_t q_stride, int64_t q_bstride, int64_t kv_stride, int64_t kv_bstride,
+                    int64_t o_stride, int64_t o_bstride, int structure, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch gather for the (1,2,2) Conv3d patch embedding, causal_model.py:458-459, :775-781:

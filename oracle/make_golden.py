@@ -486,6 +486,69 @@ def gen_s1(ns):
     print("s1_2chunks_1p3b.npz", len(out), "arrays")
 
 
+def gen_s1_full(ns):
+    """BASELINE configs[1] ("S1") IN FULL at the Wan-1.3B shape: 21 latent frames = 7 chunks x (4 + 1) forwards of 4680
+    tokens against caches of 4680 ... 32760 tokens -- every cache length the benchmark times, incl. the ones where 57 %
+    of its FLOPs run.  Same settings as gen_s1; fp32 math variant of the reference plus its own bf16 run (the noise
+    floor the tolerance is stated against).  Stored: seven latent frames in full (one per chunk), per-frame sums and
+    absolute sums of all 21, the reference's per-frame bf16-vs-fp32 distance, and every 16th row of one head of the
+    first / last layer's K / V cache (rows of all seven chunks)."""
+    import time
+    shape = sfa.WAN_1_3B
+    sd = sfa.synth_state_dict(shape, seed=0)
+    H, W, F = 60, 104, 21
+    fs = (H // 2) * (W // 2)
+    g = torch.Generator().manual_seed(6161)
+    noise = bf16_randn((1, F, 16, H, W), g)
+    pe = bf16_randn((1, 512, shape.text_dim), g)
+    pe[:, 117:] = 0
+    eps = [bf16_randn((3, 16, H, W), g) for _ in range(21)]
+    out = {"weights_seed": np.array(0), "input_seed": np.array(6161), "noise_checksum": np.array(noise.double().sum().item()),
+           "pe_checksum": np.array(pe.double().sum().item()), "eps_checksum": np.array(sum(e.double().sum().item() for e in eps))}
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True,
+                                 independent_first_frame=False, num_frame_per_block=3, context_noise=0, model_kwargs={})
+    lats = {}
+    for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        t0 = time.time()
+        model = build_model(ns, shape, sd, dtype)
+        wrapper = ref_shim.build_wrapper(ns, model, 5.0)
+        sink_out = io.StringIO()
+        with contextlib.redirect_stdout(sink_out):
+            pipe = ns.CausalInferencePipeline(args, device="cpu", generator=wrapper,
+                                              text_encoder=lambda text_prompts: {"prompt_embeds": pe.to(dtype)},
+                                              vae=_IdentityVAE())
+        pipe.kv_cache1, pipe.crossattn_cache = fresh_caches(shape, 1, F * fs, dtype)
+        queue = list(eps)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, *a, **kw: queue.pop(0).to(t.dtype).reshape(t.shape)
+        try:
+            with contextlib.redirect_stdout(sink_out), torch.no_grad():
+                _, lat = pipe.inference(noise.to(dtype), ["p"], return_latents=True)
+        finally:
+            torch.randn_like = orig
+        assert not queue
+        lats[tag] = lat.float()
+        if tag == "f32":
+            out["k0_head5_f32"] = f32(pipe.kv_cache1[0]["k"][0, ::16, 5])
+            out["v29_head11_f32"] = f32(pipe.kv_cache1[29]["v"][0, ::16, 11])
+        print("s1full", tag, "latents rms %.4f" % lat.float().pow(2).mean().sqrt().item(), "%.0f s" % (time.time() - t0), flush=True)
+        del model, wrapper, pipe
+    lf, lb = lats["f32"], lats["bf16"]
+    frames = [0, 4, 8, 11, 14, 17, 20]
+    out["frames"] = np.array(frames)
+    out["lat_f32_frames"] = f32(lf[:, frames])
+    out["lat_f32_frame_sums"] = lf.double().sum(dim=(0, 2, 3, 4)).numpy()
+    out["lat_f32_frame_abs_sums"] = lf.double().abs().sum(dim=(0, 2, 3, 4)).numpy()
+    out["lat_f32_frame_norms"] = lf.double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt().numpy()
+    out["ref_bf16_vs_f32_per_frame"] = ((lb - lf).double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt()
+                                        / lf.double().pow(2).sum(dim=(0, 2, 3, 4)).sqrt()).numpy()
+    out["ref_bf16_vs_f32"] = np.array(((lb - lf).norm() / lf.norm()).item())
+    print("s1full: reference bf16 vs fp32 rel err %.4f; per frame" % float(out["ref_bf16_vs_f32"]),
+          np.array2string(out["ref_bf16_vs_f32_per_frame"], precision=4))
+    np.savez_compressed(os.path.join(GOLD, "s1_full_clip_1p3b.npz"), **out)
+    print("s1_full_clip_1p3b.npz", len(out), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -508,6 +571,8 @@ def main():
             gen_tconfig(ns)
         if "s1" in todo:
             gen_s1(ns)
+        if "s1full" in todo:
+            gen_s1_full(ns)
 
 
 if __name__ == "__main__":

@@ -21,12 +21,12 @@ from .text_encoder import WanTextEncoder, UMT5Encoder, relative_position_buckets
 from . import unipc  # noqa: F401
 from .diffusion_pipeline import CausalDiffusionInferencePipeline  # noqa: F401
 from .unipc import FlowUniPCMultistepScheduler  # noqa: F401
-from . import ops, _lib  # noqa: F401
+from . import ops, _lib, torch_ops, text_encoder  # noqa: F401
 
 __all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict",
            "param_shapes", "merge_lora", "strip_prefix", "CachePlan", "plan_cache_update",
            "FlowMatchScheduler", "WanDiffusionWrapper", "CausalInferencePipeline",
-           "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "RolloutPool", "ops",
+           "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "RolloutPool", "ops", "torch_ops",
            "VaeShape", "WAN_VAE", "VAE_REDUCED", "synth_vae_state_dict", "vae_param_shapes", "WanVAEWrapper",
            "WanVAEDecoder", "repack_conv", "T5Shape", "UMT5_XXL", "T5_REDUCED", "synth_t5_state_dict", "t5_param_shapes",
            "WanTextEncoder", "UMT5Encoder", "relative_position_buckets", "FlowUniPCMultistepScheduler", "CausalDiffusionInferencePipeline"]

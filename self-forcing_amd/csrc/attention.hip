@@ -20,7 +20,6 @@
 // LDS image of a [64 keys][128 d] bf16 tile: 256-byte rows, the 16-byte chunk `ch` of row `row`
 // lives at chunk ch ^ (((row&3)<<2) | ((row>>2)&3)); this one image serves the row reads
 // (ds_read_b128, K) and the transposed reads (V) without bank conflicts.
-#include <cstdlib>
 #include <type_traits>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
@@ -28,12 +27,6 @@
 #define SF_R64_INC "attention_r64_asm.inc"   // timing-only ablation builds substitute their own (tools/gen_attention_r64.py --abl)
 #endif
 #include SF_R64_INC
-#ifdef SF_WITH_WS_KERNEL                     // experimental warp-specialised structure: tools/probes/build_ws_abl.sh only
-#ifndef SF_WS_INC
-#define SF_WS_INC "attention_ws_asm.inc"    // tools/gen_attention_ws.py
-#endif
-#include SF_WS_INC
-#endif
 
 namespace {
 
@@ -730,103 +723,12 @@ __global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
 }
 
 
-#ifdef SF_WITH_WS_KERNEL
-// ------------------------------------------------------------------------------------------
-// Warp-specialised structure: the 64 query rows of a wave pair are split by ROLE instead of by rows -- waves
-// 0-3 compute scores and softmax (role A), waves 4-7, which share the SIMDs with them pairwise, the P.V products,
-// the LDS-DMA requests and the output (role B); the bf16 P^T fragments travel through LDS.  Each role fits in
-// half a SIMD's registers, so the two in-order streams hide each other's non-MFMA instructions while every K /
-// V^T fragment is still read once per 64 rows.  Body: tools/gen_attention_ws.py (generated assembly).
-__global__ __launch_bounds__(512) void attention_ws_kernel(AttP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pw = wave & 3;                     // wave pair = 64-row block of the 256-row tile
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int bh = wg / p.q_tiles, qt = wg - bh * p.q_tiles;
-  const int b = bh / p.H, head = bh - b * p.H;
-  const bf16_t* qbase = p.q + (long)b * p.q_bstride + head * HD;
-  const bf16_t* kbase = p.k + (long)b * p.kv_bstride + head * HD;
-  const bf16_t* vbase = p.v + (long)b * p.kv_bstride + head * HD;
-  bf16_t* obase = p.o + (long)b * p.o_bstride + head * HD;
-
-  const int r32 = lane & 31, hh = lane >> 5;
-  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-  unsigned prm[SF_WS_N_PARAM];
-  {
-    const int x = hh ^ (((r32 & 3) << 2) | ((r32 >> 2) & 3));
-#pragma unroll
-    for (int s = 0; s < 8; ++s) prm[s] = lds_base + 256 * r32 + 16 * ((2 * s) ^ x);
-    const int g16 = lane >> 4, i16 = lane & 15;
-    const int tq = i16 >> 2, tp = i16 & 3;
-    const int y = 2 * (g16 & 1) + (tp >> 1);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      prm[8 + db] = lds_base + 256 * (4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ hh)) + 8 * (tp & 1);
-      prm[12 + db] = lds_base + 256 * (8 + 4 * hh + tq) + 16 * (4 * (db ^ tq) + (y ^ (hh + 2))) + 8 * (tp & 1);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {   // LDS-DMA pieces 4 pw + i of a K / V tile (issued by the role-B wave of the pair)
-      const int row = (pw * 4 + i) * 4 + (lane >> 4);
-      const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-      prm[16 + i] = (unsigned)(((long)row * p.kv_stride + chunk * 8) * 2);
-    }
-    unsigned valid = 0;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      const int qrow = qt * QT64 + pw * 64 + qb * 32 + r32;
-      const unsigned long long qa = (unsigned long long)(qbase + (long)min(qrow, p.Lq - 1) * p.q_stride + 8 * hh);
-      const unsigned long long oa = (unsigned long long)(obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 4 * hh);
-      prm[20 + 2 * qb] = (unsigned)qa; prm[21 + 2 * qb] = (unsigned)(qa >> 32);
-      prm[24 + 2 * qb] = (unsigned)oa; prm[25 + 2 * qb] = (unsigned)(oa >> 32);
-      if (qrow < p.Lq) valid |= 1u << qb;
-    }
-    prm[28] = valid;
-    prm[29] = lds_base + SF_WS_P_BASE + pw * 8192 + lane * 16;
-    prm[30] = lds_base + SF_WS_H_BASE + pw * 1536 + lane * 4;
-    prm[31] = lds_base + SF_WS_H_BASE + 12288 + pw * 512 + lane * 4;
-  }
-  unsigned* pl = reinterpret_cast<unsigned*>(smem);
-#pragma unroll
-  for (int j = 0; j < SF_WS_N_PARAM; ++j) pl[j * 512 + tid] = prm[j];
-
-  const unsigned kv_bytes = (unsigned)(((long)(p.Lk - 1) * p.kv_stride + HD) * 2);
-  auto make_srd = [&](const bf16_t* base) {
-    const unsigned long long a64 = (unsigned long long)base;
-    u32x4 d;
-    d[0] = __builtin_amdgcn_readfirstlane((unsigned)a64);
-    d[1] = __builtin_amdgcn_readfirstlane((unsigned)(a64 >> 32) & 0xFFFFu);
-    d[2] = __builtin_amdgcn_readfirstlane(kv_bytes);
-    d[3] = 0x00020000u;
-    return d;
-  };
-  const u32x4 k_srd = make_srd(kbase), v_srd = make_srd(vbase);
-  const unsigned tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)((long)KT * p.kv_stride * 2));
-  const int ntiles = __builtin_amdgcn_readfirstlane((p.Lk + KT - 1) / KT);
-  const int lk = __builtin_amdgcn_readfirstlane(p.Lk);
-  const unsigned cbits = __builtin_amdgcn_readfirstlane(__float_as_uint(p.scale_log2));
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)pw * 4096u);
-  const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_base);
-  const unsigned role = __builtin_amdgcn_readfirstlane((unsigned)wave >> 2);
-  const unsigned tid4 = lds_base + 4u * (unsigned)tid;
-  asm volatile(SF_WS_ASM_BODY
-               :
-               : "s"(k_srd), "s"(v_srd), "s"(tile_bytes), "s"(ntiles), "s"(lk), "s"(cbits), "s"(lds_wave), "v"(tid4), "s"(lds_b), "s"(role)
-               : SF_WS_CLOBBERS);
-}
-
-
-#endif  // SF_WITH_WS_KERNEL
 
 }  // namespace
 
-extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
-                            int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
-                            int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, void* stream) {
+extern "C" int sf_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
+                               int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
+                               int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, int structure, void* stream) {
   SF_CHECK(q && k && v && out, "sf_attention: null tensor");
   SF_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sf_attention: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
   SF_CHECK(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0, "sf_attention: strides must keep 16-byte row alignment");
@@ -834,6 +736,7 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   SF_CHECK(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),
            "sf_attention: misaligned tensor");
   SF_CHECK(((long)(Lk - 1) * kv_stride + 128) * 2 < (1L << 31), "sf_attention: one (batch, head) K/V slab must span < 2 GiB");
+  SF_CHECK(structure >= SF_ATTN_AUTO && structure <= SF_ATTN_W4, "sf_attention: unknown structure %d", structure);
   AttP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)out;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
@@ -841,29 +744,17 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
   p.o_stride = o_stride; p.o_bstride = o_bstride;
   p.q_tiles = (Lq + QT - 1) / QT;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
-  // 256-row / 8-wave structure when it fills most of the chip's 256 CUs in whole rounds, else
-  // 128-row / 4-wave workgroups (two per CU)
-  // Structure: long key sequences that fill the chip run the hand-scheduled 64-rows-per-wave kernel;
-  // short ones (cross-attention: 8 key tiles) the 8-wave anti-phase kernel; small problems the 4-wave one.
-  // Environment switches (A/B timing and tests only): SF_ATTN_R64 / SF_ATTN_W8 / SF_ATTN_W4 force a structure.
+  // Structure (SF_ATTN_AUTO): long key sequences that fill the chip run the hand-scheduled 64-rows-per-wave
+  // kernel; short ones that fill it (cross-attention: 8 key tiles) the 8-wave anti-phase kernel (256 query rows
+  // per workgroup); small problems the 4-wave one (128 rows, two workgroups per CU).  Every structure is correct
+  // for every shape; the explicit values exist for tests and A/B timing.
   const long nwg64 = (long)((Lq + QT64 - 1) / QT64) * H * B;
-#ifdef SF_WITH_WS_KERNEL
-  if (getenv("SF_ATTN_WS")) {   // bring-up switch of the warp-specialised kernel
+  const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
+  if (structure == SF_ATTN_AUTO)
+    structure = (nwg64 >= 192 && Lk > 1024) ? SF_ATTN_R64 : nwg8 >= 192 ? SF_ATTN_W8 : SF_ATTN_W4;
+  if (structure == SF_ATTN_R64) {
     p.q_tiles = (Lq + QT64 - 1) / QT64;
-    static bool attr_ws = false;
-    if (!attr_ws) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_WS_LDS_BYTES);
-      attr_ws = true;
-    }
-    hipLaunchKernelGGL(attention_ws_kernel, dim3((unsigned)nwg64), dim3(512), SF_WS_LDS_BYTES, (hipStream_t)stream, p);
-    SF_HIP_LAUNCH_CHECK("sf_attention");
-    return 0;
-  }
-#endif
-  const bool forced = getenv("SF_ATTN_W8") || getenv("SF_ATTN_W4");
-  if (getenv("SF_ATTN_R64") || (!forced && nwg64 >= 192 && Lk > 1024)) {
-    p.q_tiles = (Lq + QT64 - 1) / QT64;
-    static bool attr = false;
+    static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent; no other state is kept)
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);
       attr = true;
@@ -872,8 +763,7 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
     SF_HIP_LAUNCH_CHECK("sf_attention");
     return 0;
   }
-  const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
-  if ((nwg8 >= 192 && !getenv("SF_ATTN_W4")) || getenv("SF_ATTN_W8")) {   // env switches: A/B timing and tests only
+  if (structure == SF_ATTN_W8) {
     p.q_tiles = (Lq + QT8 - 1) / QT8;
     if (Lk > 1024)
       hipLaunchKernelGGL(attention_w8_kernel<0>, dim3((unsigned)nwg8), dim3(ATT8_THREADS), ATT8_LDS, (hipStream_t)stream, p);
@@ -890,4 +780,11 @@ extern "C" int sf_attention(const void* q, const void* k, const void* v, void* o
     hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)nwg), dim3(ATT_THREADS), ATT_LDS, (hipStream_t)stream, p);
   SF_HIP_LAUNCH_CHECK("sf_attention");
   return 0;
+}
+
+extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
+                            int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
+                            int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, void* stream) {
+  return sf_attention_ex(q, k, v, out, B, H, Lq, Lk, q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride,
+                         SF_ATTN_AUTO, stream);
 }

@@ -13,7 +13,6 @@
 // bank-conflict free.  The MFMA is issued as D = W_frag x X_frag (operands swapped) so that each
 // lane ends up with 4 CONSECUTIVE output columns of one row: 8-byte bf16x4 stores/loads in the
 // epilogue instead of 2-byte scattered ones.
-#include <cstdlib>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
 
@@ -487,13 +486,12 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   p.tiles_m = (a->M + BM - 1) / BM;
   // wide outputs whose 256 x 256 tiles fill the chip in nearly whole rounds take the large-tile structure
-  // (env SF_GEMM_BIG=1/0 forces / forbids it: A/B timing and tests only)
+  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_T256, "sf_gemm_bf16: unknown structure %d", a->structure);
   {
     const long tb = (long)((a->M + BBM - 1) / BBM) * ((a->N + BBN - 1) / BBN);
     const long rounds = (tb + 255) / 256;
-    const char* env = getenv("SF_GEMM_BIG");
     bool big = a->N >= 2048 && a->M >= 1024 && tb >= 512 && (double)tb / (rounds * 256) >= 0.8;
-    if (env) big = env[0] == '1';
+    if (a->structure != SF_GEMM_AUTO) big = a->structure == SF_GEMM_T256;
     if (a->batch > 1) big = false;
     if (big && a->epilogue != SF_EPI_F32) {
       switch (a->epilogue) {

@@ -77,10 +77,14 @@ class CausalDiffusionInferencePipeline(torch.nn.Module):
         self.device = torch.device(device)
         self.generator = WanDiffusionWrapper(**getattr(args, "model_kwargs", {}), is_causal=True, device=device) \
             if generator is None else generator
-        if text_encoder is None or vae is None:
-            raise NotImplementedError(
-                "inject text_encoder= and vae= (self_forcing_amd.WanTextEncoder / WanVAEWrapper, or the synthetic "
-                "stand-ins of self_forcing_amd.harness)")
+        # as the reference (causal_inference.py:19-23): build the default components when none is injected; they load
+        # the reference's default checkpoints (weights-only) and raise FileNotFoundError when those are absent
+        if text_encoder is None:
+            from .text_encoder import WanTextEncoder
+            text_encoder = WanTextEncoder(device=device)
+        if vae is None:
+            from .vae import WanVAEWrapper
+            vae = WanVAEWrapper(device=device)
         self.text_encoder = text_encoder
         self.vae = vae
         self.image_encoder = image_encoder      # accepted for signature parity; the CLIP front end is out of scope

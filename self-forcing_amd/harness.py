@@ -1,6 +1,8 @@
-"""Stand-ins for the two components that sit either side of the hot path and are out of scope
-here: the umT5 text encoder and the Wan VAE.  The reference's
-pipeline constructor accepts injected ones (pipeline/causal_inference.py:14-23)."""
+"""Synthetic stand-ins for the two components either side of the DiT rollout -- the umT5 text encoder and
+the Wan VAE -- for benchmarks and tests that time / check the rollout alone (BASELINE.json's timed region ends at
+the last latent).  The real ones are `self_forcing_amd.WanTextEncoder` (text_encoder.py) and
+`self_forcing_amd.WanVAEWrapper` (vae.py); the pipeline constructors accept either kind injected, as the
+reference's do (pipeline/causal_inference.py:14-23)."""
 from __future__ import annotations
 
 import zlib

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, torch_ops
 from .kvcache import CachePlan
 from .weights import WanShape, param_shapes
 
@@ -54,6 +54,7 @@ class CausalWanModel:
         self._keep: List[Tensor] = []      # every device tensor the C struct points into
         self._workspaces: Dict[tuple, Tensor] = {}
         self._load(state_dict, sched_sigmas, sched_timesteps)
+        self._handle = torch_ops.register_model(self)
 
     # ---------------------------------------------------------------------------------
     def _dev(self, t: Tensor) -> Tensor:
@@ -132,36 +133,16 @@ class CausalWanModel:
         return ws
 
     def forward(self, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], init_cross: bool,
-                k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cache_tokens: int, plan: CachePlan, start_frame: int,
-                evict_scratch: Optional[Tensor] = None, cache_only: bool = False, add_condition: Optional[Tensor] = None):
-        """noisy [B,F,in_dim,H,W] bf16 (contiguous); timestep [B,G] float32|int64 on device;
-        *_ptrs: ctypes arrays of per-layer cache pointers.  Returns (flow, x0) [B,F,out_dim,H,W]."""
+                k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor], plan: CachePlan,
+                start_frame: int, evict_scratch: Optional[Tensor] = None, cache_only: bool = False,
+                add_condition: Optional[Tensor] = None):
+        """noisy [B,F,in_dim,H,W] bf16 (contiguous); timestep [B,G] float32|int64 on device; *_cache: per-layer cache
+        tensors (mutated in place).  Returns (flow, x0) [B,F,out_dim,H,W], or (None, None) with cache_only.
+        ONE custom-op call: torch.ops.sf_hip.dit_forward -> sf_dit_forward."""
         B, F, Cin, H, W = noisy.shape
-        G = timestep.shape[1]
-        a = _lib.ForwardArgs()
-        a.batch, a.frames, a.lat_h, a.lat_w, a.groups = B, F, H, W, G
-        a.noisy = noisy.data_ptr()
-        a.timestep = timestep.data_ptr()
-        a.t_is_int64 = 1 if timestep.dtype == torch.int64 else 0
-        a.prompt_embeds = prompt_embeds.data_ptr() if prompt_embeds is not None else None
-        a.init_cross = 1 if init_cross else 0
-        a.add_condition = add_condition.data_ptr() if add_condition is not None else None
-        a.k_cache_host, a.v_cache_host, a.ck_cache_host, a.cv_cache_host = k_ptrs, v_ptrs, ck_ptrs, cv_ptrs
-        a.cache_tokens = cache_tokens
-        a.sink_tokens, a.evict, a.keep = plan.sink, plan.evict, plan.keep
-        a.write_start, a.attn_start, a.attn_end = plan.write_start, plan.attn_start, plan.local_end
-        a.start_frame = start_frame
-        if evict_scratch is not None:
-            a.evict_scratch = evict_scratch.data_ptr()
-            a.evict_scratch_bytes = evict_scratch.numel() * evict_scratch.element_size()
-        flow = x0 = None
-        a.cache_only = 1 if cache_only else 0
-        if not cache_only:
-            flow = torch.empty(B, F, self.shape.out_dim, H, W, dtype=torch.bfloat16, device=self.device)
-            x0 = torch.empty_like(flow)
-            a.flow_out, a.x0_out = flow.data_ptr(), x0.data_ptr()
-        ws = self.workspace(B, F, H, W, G)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        _lib.check(_lib.lib().sf_dit_forward(C.byref(self.cmodel), C.byref(a), torch.cuda.current_stream().cuda_stream),
-                   "sf_dit_forward")
-        return flow, x0
+        ws = self.workspace(B, F, H, W, timestep.shape[1])
+        flow, x0 = torch.ops.sf_hip.dit_forward(
+            self._handle, noisy, timestep, prompt_embeds, add_condition, k_cache, v_cache, ck_cache, cv_cache, ws, evict_scratch,
+            bool(init_cross), bool(cache_only), plan.sink, plan.evict, plan.keep, plan.write_start, plan.attn_start, plan.local_end,
+            start_frame)
+        return (None, None) if cache_only else (flow, x0)

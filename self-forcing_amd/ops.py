@@ -1,7 +1,9 @@
 """Per-kernel Python entry points over the C-ABI (torch tensors in, torch tensors out).
 
 torch is used only for device memory and the current stream; every computation below runs in
-the hand-written HIP kernels of csrc/.  All functions require CUDA(ROCm) bf16 tensors and
+the hand-written HIP kernels of csrc/.  The operators that also exist as PyTorch custom ops (`torch_ops.py`:
+gemm, attention, lincomb, add_noise) are called through `torch.ops.sf_hip.*`; the remaining per-kernel test entry
+points bind the C-ABI directly.  All functions require CUDA(ROCm) bf16 tensors and
 raise if the library is missing -- there is no fallback path.
 """
 from __future__ import annotations
@@ -12,6 +14,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from . import torch_ops  # noqa: F401  (registers torch.ops.sf_hip.*)
 from ._lib import (ACT_GELU, ACT_NONE, ACT_SILU, CONV_BIAS, CONV_BIAS_CLAMP_F32, CONV_BIAS_RESID, EPI_BIAS,
                    EPI_BIAS_GATE_RESID, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_F32, ConvArgs, GemmArgs, check, lib)
 
@@ -54,37 +57,14 @@ def _timestep(t: Tensor):
 # --------------------------------------------------------------------------------------
 def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: str = "bias",
          resid: Optional[Tensor] = None, gate_mod: Optional[Tensor] = None, gate_e0: Optional[Tensor] = None,
-         rows_per_group: int = 1, out: Optional[Tensor] = None) -> Tensor:
-    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  gate_e0: [groups, N] view (row stride free)."""
+         rows_per_group: int = 1, out: Optional[Tensor] = None, structure: str = "auto") -> Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  gate_e0: [groups, N] view (row stride free).
+    `structure` ("auto" | "t128" | "t256") forces a tiling (tests / A-B timing)."""
     a, w = _rows(a, "a"), _rows(w, "w")
-    M, K = a.shape
-    N = w.shape[0]
-    if w.shape[1] != K:
-        raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
-    if epilogue == "f32":   # raw fp32 accumulators (no bias)
-        if out is None:
-            out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-        if out.dtype != torch.float32 or out.dim() != 2 or out.stride(1) != 1:
-            raise ValueError("gemm: the f32 epilogue needs a float32 2-D output with contiguous rows")
-    else:
-        if out is None:
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
-        _rows(out, "out")
-    g = GemmArgs()
-    g.a, g.w, g.bias, g.out = a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr()
-    g.M, g.N, g.K = M, N, K
-    g.lda, g.ldw, g.ldo = a.stride(0), w.stride(0), out.stride(0)
-    g.epilogue = _EPI[epilogue]
-    g.rows_per_group = rows_per_group
-    if resid is not None:
-        _rows(resid, "resid")
-        g.resid, g.ldr = resid.data_ptr(), resid.stride(0)
-    if gate_mod is not None:
-        g.gate_mod = _bf16(gate_mod, "gate_mod").data_ptr()
-    if gate_e0 is not None:
-        _rows(gate_e0, "gate_e0")
-        g.gate_e0, g.gate_group_stride = gate_e0.data_ptr(), gate_e0.stride(0)
-    check(lib().sf_gemm_bf16(g, stream_handle()), "sf_gemm_bf16")
+    epi, st = _EPI[epilogue], _lib.GEMM_STRUCTURES[structure]
+    if out is None:
+        return torch.ops.sf_hip.gemm(a, w, bias, epi, resid, gate_mod, gate_e0, rows_per_group, st)
+    torch.ops.sf_hip.gemm_out(out, a, w, bias, epi, resid, gate_mod, gate_e0, rows_per_group, st)
     return out
 
 
@@ -161,20 +141,10 @@ def kv_evict(cache: Tensor, sink: int, evict: int, keep: int, scratch: Tensor) -
                             scratch.numel() * scratch.element_size(), stream_handle()), "sf_kv_evict")
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
-    """q [B,Lq,H,128], k/v [B,Lk,H,128] (token/batch strides free, [H,D] contiguous) -> [B,Lq,H,128]."""
-    for n, t in (("q", q), ("k", k), ("v", v)):
-        _bf16(t, n)
-        if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1 or t.stride(2) != 128:
-            raise ValueError(f"attention: {n} must be [B, L, H, 128] with contiguous heads, got {tuple(t.shape)} {t.stride()}")
-    B, Lq, H, D = q.shape
-    Lk = k.shape[1]
-    if k.stride() != v.stride() or k.shape != v.shape:
-        raise ValueError("attention: k and v must share shape and strides")
-    out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
-    check(lib().sf_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Lq, Lk, q.stride(1), q.stride(0),
-                             k.stride(1), k.stride(0), out.stride(1), out.stride(0), stream_handle()), "sf_attention")
-    return out
+def attention(q: Tensor, k: Tensor, v: Tensor, structure: str = "auto") -> Tensor:
+    """q [B,Lq,H,128], k/v [B,Lk,H,128] (token/batch strides free, [H,D] contiguous) -> [B,Lq,H,128].
+    `structure` ("auto" | "r64" | "w8" | "w4") forces a kernel structure (tests / A-B timing)."""
+    return torch.ops.sf_hip.attention(q, k, v, _lib.ATTN_STRUCTURES[structure])
 
 
 def patchify(x: Tensor) -> Tensor:
@@ -204,15 +174,10 @@ def add_noise(x0: Tensor, eps: Tensor, timestep: Tensor, sigmas: Tensor, timeste
     """(1 - sigma_t) x0 + sigma_t eps; x0/eps [N, ...], timestep [N]."""
     x0 = _bf16(x0, "x0").contiguous()
     eps = _bf16(eps, "eps").contiguous()
-    tt, is64 = _timestep(timestep.flatten())
-    n = x0.shape[0]
-    if tt.numel() != n:
-        raise ValueError(f"add_noise: {n} samples but {tt.numel()} timesteps")
-    inner = x0.numel() // n
-    out = torch.empty_like(eps)
-    check(lib().sf_add_noise(x0.data_ptr(), eps.data_ptr(), tt.data_ptr(), is64, sigmas.data_ptr(), timesteps.data_ptr(),
-                             sigmas.numel(), out.data_ptr(), n, inner, stream_handle()), "sf_add_noise")
-    return out
+    tt, _ = _timestep(timestep.flatten())
+    if tt.numel() != x0.shape[0]:
+        raise ValueError(f"add_noise: {x0.shape[0]} samples but {tt.numel()} timesteps")
+    return torch.ops.sf_hip.add_noise(x0, eps, tt, sigmas, timesteps)
 
 
 LINCOMB_MAX = 6
@@ -224,17 +189,10 @@ def lincomb(tensors, coefs, out: Optional[Tensor] = None) -> Tensor:
     if not 1 <= len(tensors) <= LINCOMB_MAX or len(tensors) != len(coefs):
         raise ValueError(f"lincomb: 1..{LINCOMB_MAX} tensors with one coefficient each, got {len(tensors)} / {len(coefs)}")
     xs = [_bf16(t, f"tensors[{i}]").contiguous() for i, t in enumerate(tensors)]
-    for t in xs[1:]:
-        if t.shape != xs[0].shape or t.device != xs[0].device:
-            raise ValueError("lincomb: tensors must share shape and device")
+    cf = [float(c) for c in coefs]
     if out is None:
-        out = torch.empty_like(xs[0])
-    elif out.shape != xs[0].shape or out.dtype != torch.bfloat16 or not out.is_contiguous():
-        raise ValueError("lincomb: out must be a contiguous bf16 tensor of the inputs' shape")
-    n = len(xs)
-    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in xs])
-    cf = (C.c_float * n)(*[float(c) for c in coefs])
-    check(lib().sf_lincomb_bf16(out.data_ptr(), ptrs, cf, n, xs[0].numel(), stream_handle()), "sf_lincomb_bf16")
+        return torch.ops.sf_hip.lincomb(xs, cf)
+    torch.ops.sf_hip.lincomb_out(out, xs, cf)
     return out
 
 

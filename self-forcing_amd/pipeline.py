@@ -8,9 +8,11 @@ low_memory=False)`, same attributes read by the reference's other callers (`kv_c
 
 What differs: the five constants the reference hard-codes for Wan-1.3B/480p
 (30 blocks, 1560 tokens/frame, 12x128 heads, 32760-token cache; causal_inference.py:33-34,
-:288-293) are derived from the generator's shape and the latent size; the text encoder and VAE
-are outside this hot path and must be injected (a synthetic encoder / identity VAE live in
-`harness.py`); the per-step `print` is dropped; `low_memory` is accepted and ignored (288 GB HBM).
+:288-293) are derived from the generator's shape and the latent size; when no text encoder / VAE is
+injected, `WanTextEncoder()` / `WanVAEWrapper()` are built from the reference's default local
+checkpoint paths as causal_inference.py:19-23 does (weights-only loads; FileNotFoundError when the
+files are absent -- benchmarks and tests inject the stand-ins of `harness.py` or seeded-weight
+instances instead); the per-step `print` is dropped; `low_memory` is accepted and ignored (288 GB HBM).
 """
 from __future__ import annotations
 
@@ -27,10 +29,14 @@ class CausalInferencePipeline(torch.nn.Module):
         self.device_ = torch.device(device)
         self.generator = WanDiffusionWrapper(**getattr(args, "model_kwargs", {}), is_causal=True, device=device) \
             if generator is None else generator
-        if text_encoder is None or vae is None:
-            raise NotImplementedError(
-                "the umT5 text encoder and the Wan VAE are outside this hot path: inject text_encoder= and vae= "
-                "(see self_forcing_amd.harness.SyntheticTextEncoder / IdentityVAE)")
+        # as the reference (causal_inference.py:19-23): build the default components when none is injected; they load
+        # the reference's default checkpoints (weights-only) and raise FileNotFoundError when those are absent
+        if text_encoder is None:
+            from .text_encoder import WanTextEncoder
+            text_encoder = WanTextEncoder(device=device)
+        if vae is None:
+            from .vae import WanVAEWrapper
+            vae = WanVAEWrapper(device=device)
         self.text_encoder = text_encoder
         self.vae = vae
 

@@ -20,7 +20,7 @@ from typing import Callable, Dict, List, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, torch_ops
 from .t5_weights import T5Shape, UMT5_XXL, t5_param_shapes
 
 Tensor = torch.Tensor
@@ -79,6 +79,7 @@ class UMT5Encoder:
         m.layers_host = C.cast(layers, C.POINTER(_lib.T5Layer))
         m.final_norm_w = self._dev(sd["norm.weight"]).data_ptr()
         self.cmodel = m
+        self._handle = torch_ops.register_model(self)
 
     def _dev(self, t: Tensor) -> Tensor:
         t = t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
@@ -107,19 +108,66 @@ class UMT5Encoder:
                 _lib.check(-1, "sf_t5_workspace_bytes")
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device)
         ws = self._ws[key]
-        out = torch.empty(B, L, self.shape.dim, dtype=torch.bfloat16, device=self.device)
-        _lib.check(_lib.lib().sf_t5_encode(C.byref(self.cmodel), ids.data_ptr(), mask.data_ptr(), self._buckets[L].data_ptr(), B, L,
-                                          out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream),
-                   "sf_t5_encode")
-        return out
+        return torch.ops.sf_hip.t5_encode(self._handle, ids, mask, self._buckets[L], ws)
+
+
+# default locations of the reference (utils/wan_wrapper.py:26-35)
+T5_CHECKPOINTS = ("/tmp/models_t5_umt5-xxl-enc-bf16.pth", "wan_models/Wan2.1-T2V-1.3B/models_t5_umt5-xxl-enc-bf16.pth")
+T5_TOKENIZER_DIR = "wan_models/Wan2.1-T2V-1.3B/google/umt5-xxl/"
+
+
+def load_t5_checkpoint(path: Optional[str] = None) -> Dict[str, Tensor]:
+    """The encoder tensors of `models_t5_umt5-xxl-enc-bf16.pth` from the reference's default locations.  Loaded with
+    `weights_only=True` (the reference itself unpickles with weights_only=False, wan_wrapper.py:30-32)."""
+    import os
+    for cand in ([path] if path else T5_CHECKPOINTS):
+        if os.path.exists(cand):
+            return torch.load(cand, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(
+        f"umT5 checkpoint not found (looked at {[path] if path else list(T5_CHECKPOINTS)}): download it as the reference's "
+        "README describes, or construct WanTextEncoder(state_dict=...) / inject a text_encoder= into the pipeline")
+
+
+class HuggingfaceTokenizer:
+    """`HuggingfaceTokenizer(name, seq_len=512, clean='whitespace')` of wan/modules/tokenizers.py:38-73 for a LOCAL
+    tokenizer directory: html-unescape twice, strip, collapse whitespace, then the sentencepiece tokenizer with
+    padding / truncation to `seq_len`.  (`ftfy.fix_text`, the first cleaning step of the reference, is not installed
+    here and is skipped: it only repairs mojibake.)"""
+
+    def __init__(self, name: str = T5_TOKENIZER_DIR, seq_len: int = 512):
+        import os
+        if not os.path.isdir(name):
+            raise FileNotFoundError(f"tokenizer directory {name!r} not found; pass tokenizer=callable(texts) -> (ids, mask)")
+        from transformers import AutoTokenizer
+        self.tokenizer = AutoTokenizer.from_pretrained(name, local_files_only=True)
+        self.seq_len = seq_len
+
+    @staticmethod
+    def clean(text: str) -> str:
+        import html
+        import re
+        return re.sub(r"\s+", " ", html.unescape(html.unescape(text)).strip()).strip()
+
+    def __call__(self, texts):
+        if isinstance(texts, str):
+            texts = [texts]
+        out = self.tokenizer([self.clean(t) for t in texts], return_tensors="pt", padding="max_length", truncation=True,
+                             max_length=self.seq_len, add_special_tokens=True)
+        return out.input_ids, out.attention_mask
 
 
 class WanTextEncoder(torch.nn.Module):
-    """Drop-in for the reference's `WanTextEncoder` (utils/wan_wrapper.py:15-55)."""
+    """Drop-in for the reference's `WanTextEncoder` (utils/wan_wrapper.py:15-55).  `WanTextEncoder()` -- no arguments,
+    as the reference's pipelines construct it -- loads the checkpoint and the tokenizer from the reference's default
+    local paths (weights-only) and raises FileNotFoundError when they are absent; there is no download."""
 
-    def __init__(self, state_dict: Dict[str, Tensor], tokenizer: Optional[Callable] = None, device="cuda",
-                 shape: T5Shape = UMT5_XXL):
+    def __init__(self, state_dict: Optional[Dict[str, Tensor]] = None, tokenizer: Optional[Callable] = None, device="cuda",
+                 shape: T5Shape = UMT5_XXL, checkpoint_path: Optional[str] = None):
         super().__init__()
+        if state_dict is None:
+            state_dict = load_t5_checkpoint(checkpoint_path)
+            if tokenizer is None:
+                tokenizer = HuggingfaceTokenizer()
         self.text_encoder = UMT5Encoder(shape, state_dict, device)
         self.tokenizer = tokenizer
 

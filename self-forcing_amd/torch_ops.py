@@ -1,0 +1,309 @@
+"""PyTorch custom operators over the C-ABI: `torch.ops.sf_hip.*` take Tensors (BASELINE north_star: "Python host code
+calling HIP through PyTorch-ROCm custom ops over a thin C-ABI").
+
+Every operator below is a thin shim: it validates shapes / dtypes, allocates the outputs with torch, reads the current
+HIP stream, and makes ONE call into `libsf_hip.so` (`include/sf_hip.h`) with raw device pointers.  Registered with
+`torch.library.custom_op`, so each has a schema (mutated arguments declared), a fake ("meta") implementation for
+tracing, and is opaque-but-legal to `torch.compile` -- which the reference's second caller wraps around the generator
+(demo.py:340); a bare ctypes call would be a graph break with unknown side effects.  `ops.py` (per-kernel wrappers),
+`model.py` (the fused forward), `vae.py`, `text_encoder.py` route through these.
+
+    sf_hip::attention(q, k, v, structure) -> out
+    sf_hip::gemm(a, w, bias?, epilogue, resid?, gate_mod?, gate_e0?, rows_per_group, structure) -> out
+    sf_hip::gemm_out(out!, a, w, ...) -> ()                         (caller-provided / aliased output)
+    sf_hip::lincomb(tensors[], coefs[]) -> out ;  sf_hip::lincomb_out(out!, tensors[], coefs[]) -> ()
+    sf_hip::add_noise(x0, eps, timestep, sigmas, timesteps) -> out
+    sf_hip::dit_forward(model, noisy, timestep, prompt_embeds?, add_condition?, k_cache![], v_cache![], ck_cache![],
+                        cv_cache![], workspace!, evict_scratch!?, ...) -> (flow, x0)
+    sf_hip::vae_decode_frame(model, state!, scratch!, z, out!, h, w, first) -> ()
+    sf_hip::t5_encode(model, ids, mask, buckets, workspace!) -> out
+
+Models (weights + C descriptors) are Python objects that own device memory; operators take an integer HANDLE from
+`register_model` (a constant to a tracer).  There is no CPU implementation: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch.library import custom_op
+
+from . import _lib
+
+Tensor = torch.Tensor
+NAMESPACE = "sf_hip"
+
+_MODELS: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDictionary()
+
+
+def register_model(obj) -> int:
+    """Handle of a model object (CausalWanModel / WanVAEDecoder / UMT5Encoder) for the operators that need its weights."""
+    h = id(obj)
+    _MODELS[h] = obj
+    return h
+
+
+def _model(handle: int):
+    try:
+        return _MODELS[handle]
+    except KeyError:
+        raise RuntimeError(f"sf_hip: model handle {handle} is not registered (or its owner was freed)") from None
+
+
+def _stream(t: Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(t: Tensor, name: str, dtype=torch.bfloat16) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA/ROCm tensor (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ attention
+@custom_op(f"{NAMESPACE}::attention", mutates_args=())
+def attention(q: Tensor, k: Tensor, v: Tensor, structure: int = 0) -> Tensor:
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _need_gpu(t, n)
+        if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1 or t.stride(2) != 128:
+            raise ValueError(f"attention: {n} must be [B, L, H, 128] with contiguous heads, got {tuple(t.shape)} {t.stride()}")
+    B, Lq, H, D = q.shape
+    if k.stride() != v.stride() or k.shape != v.shape:
+        raise ValueError("attention: k and v must share shape and strides")
+    out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
+    _lib.check(_lib.lib().sf_attention_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Lq, k.shape[1],
+                                          q.stride(1), q.stride(0), k.stride(1), k.stride(0), out.stride(1), out.stride(0),
+                                          structure, _stream(q)), "sf_attention")
+    return out
+
+
+@attention.register_fake
+def _(q, k, v, structure=0):
+    return q.new_empty(q.shape)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def _gemm_launch(out: Tensor, a: Tensor, w: Tensor, bias, epilogue: int, resid, gate_mod, gate_e0, rows_per_group: int,
+                 structure: int) -> None:
+    for n, t in (("a", a), ("w", w)):
+        _need_gpu(t, n)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm: {n} must be 2-D with contiguous rows, got {tuple(t.shape)} {t.stride()}")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
+    want = torch.float32 if epilogue == _lib.EPI_F32 else torch.bfloat16
+    _need_gpu(out, "out", want)
+    if out.dim() != 2 or out.stride(1) != 1 or tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm: out must be [{M},{N}] with contiguous rows, got {tuple(out.shape)} {out.stride()}")
+    g = _lib.GemmArgs()
+    g.a, g.w, g.bias, g.out = a.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldw, g.ldo = a.stride(0), w.stride(0), out.stride(0)
+    g.epilogue, g.rows_per_group, g.structure = epilogue, rows_per_group, structure
+    if resid is not None:
+        _need_gpu(resid, "resid")
+        g.resid, g.ldr = resid.data_ptr(), resid.stride(0)
+    if gate_mod is not None:
+        _need_gpu(gate_mod, "gate_mod")
+        g.gate_mod = gate_mod.data_ptr()
+    if gate_e0 is not None:
+        _need_gpu(gate_e0, "gate_e0")
+        g.gate_e0, g.gate_group_stride = gate_e0.data_ptr(), gate_e0.stride(0)
+    _lib.check(_lib.lib().sf_gemm_bf16(g, _stream(a)), "sf_gemm_bf16")
+
+
+@custom_op(f"{NAMESPACE}::gemm", mutates_args=())
+def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, resid: Optional[Tensor], gate_mod: Optional[Tensor],
+         gate_e0: Optional[Tensor], rows_per_group: int, structure: int) -> Tensor:
+    out = torch.empty(a.shape[0], w.shape[0], dtype=torch.float32 if epilogue == _lib.EPI_F32 else torch.bfloat16, device=a.device)
+    _gemm_launch(out, a, w, bias, epilogue, resid, gate_mod, gate_e0, rows_per_group, structure)
+    return out
+
+
+@gemm.register_fake
+def _(a, w, bias, epilogue, resid, gate_mod, gate_e0, rows_per_group, structure):
+    return a.new_empty((a.shape[0], w.shape[0]), dtype=torch.float32 if epilogue == _lib.EPI_F32 else torch.bfloat16)
+
+
+@custom_op(f"{NAMESPACE}::gemm_out", mutates_args=("out",))
+def gemm_out(out: Tensor, a: Tensor, w: Tensor, bias: Optional[Tensor], epilogue: int, resid: Optional[Tensor],
+             gate_mod: Optional[Tensor], gate_e0: Optional[Tensor], rows_per_group: int, structure: int) -> None:
+    _gemm_launch(out, a, w, bias, epilogue, resid, gate_mod, gate_e0, rows_per_group, structure)
+
+
+# ------------------------------------------------------------------------------------------ lincomb / add_noise
+def _lincomb_launch(out: Tensor, tensors: Sequence[Tensor], coefs: Sequence[float]) -> None:
+    n = len(tensors)
+    if not 1 <= n <= 6 or n != len(coefs):
+        raise ValueError(f"lincomb: 1..6 tensors with one coefficient each, got {n} / {len(coefs)}")
+    for i, t in enumerate(tensors):
+        _need_gpu(t, f"tensors[{i}]")
+        if not t.is_contiguous() or t.shape != tensors[0].shape or t.device != tensors[0].device:
+            raise ValueError("lincomb: tensors must be contiguous and share shape and device")
+    if out.shape != tensors[0].shape or out.dtype != torch.bfloat16 or not out.is_contiguous():
+        raise ValueError("lincomb: out must be a contiguous bf16 tensor of the inputs' shape")
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    _lib.check(_lib.lib().sf_lincomb_bf16(out.data_ptr(), ptrs, cf, n, tensors[0].numel(), _stream(out)), "sf_lincomb_bf16")
+
+
+@custom_op(f"{NAMESPACE}::lincomb", mutates_args=())
+def lincomb(tensors: List[Tensor], coefs: List[float]) -> Tensor:
+    if not tensors:
+        raise ValueError("lincomb: 1..6 tensors with one coefficient each, got 0")
+    out = torch.empty_like(tensors[0], memory_format=torch.contiguous_format)
+    _lincomb_launch(out, tensors, coefs)
+    return out
+
+
+@lincomb.register_fake
+def _(tensors, coefs):
+    return torch.empty_like(tensors[0])
+
+
+@custom_op(f"{NAMESPACE}::lincomb_out", mutates_args=("out",))
+def lincomb_out(out: Tensor, tensors: List[Tensor], coefs: List[float]) -> None:
+    _lincomb_launch(out, tensors, coefs)
+
+
+@custom_op(f"{NAMESPACE}::add_noise", mutates_args=())
+def add_noise(x0: Tensor, eps: Tensor, timestep: Tensor, sigmas: Tensor, timesteps: Tensor) -> Tensor:
+    _need_gpu(x0, "x0"), _need_gpu(eps, "eps"), _need_gpu(sigmas, "sigmas", torch.float32), _need_gpu(timesteps, "timesteps", torch.float32)
+    if not (x0.is_contiguous() and eps.is_contiguous() and timestep.is_contiguous()):
+        raise ValueError("add_noise: contiguous tensors expected")
+    n = x0.shape[0]
+    if timestep.numel() != n or timestep.dtype not in (torch.float32, torch.int64):
+        raise ValueError(f"add_noise: {n} samples need {n} float32 / int64 timesteps, got {timestep.numel()} of {timestep.dtype}")
+    out = torch.empty_like(eps)
+    _lib.check(_lib.lib().sf_add_noise(x0.data_ptr(), eps.data_ptr(), timestep.data_ptr(), int(timestep.dtype == torch.int64),
+                                       sigmas.data_ptr(), timesteps.data_ptr(), sigmas.numel(), out.data_ptr(), n, x0.numel() // n,
+                                       _stream(x0)), "sf_add_noise")
+    return out
+
+
+@add_noise.register_fake
+def _(x0, eps, timestep, sigmas, timesteps):
+    return torch.empty_like(eps)
+
+
+# ------------------------------------------------------------------------------------------ fused DiT forward
+_TABLES: Dict[int, tuple] = {}
+
+
+def _pointer_tables(handle: int, k: Sequence[Tensor], v: Sequence[Tensor], ck: Sequence[Tensor], cv: Sequence[Tensor]):
+    """Per-layer cache pointer arrays for the C call; rebuilt only when a cache tensor was re-allocated / rebound."""
+    key = tuple(t.data_ptr() for t in k) + tuple(t.data_ptr() for t in v) + tuple(t.data_ptr() for t in ck) + tuple(t.data_ptr() for t in cv)
+    slot = (handle, torch.cuda.current_stream(k[0].device).cuda_stream)
+    hit = _TABLES.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    tabs = (arr(k), arr(v), arr(ck), arr(cv))
+    if len(_TABLES) > 64:
+        _TABLES.clear()
+    _TABLES[slot] = (key, tabs)
+    return tabs
+
+
+@custom_op(f"{NAMESPACE}::dit_forward",
+           mutates_args=("k_cache", "v_cache", "ck_cache", "cv_cache", "workspace", "evict_scratch"))
+def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], add_condition: Optional[Tensor],
+                k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor],
+                workspace: Tensor, evict_scratch: Optional[Tensor], init_cross: bool, cache_only: bool, sink: int, evict: int,
+                keep: int, write_start: int, attn_start: int, attn_end: int, start_frame: int) -> Tuple[Tensor, Tensor]:
+    """One denoiser pass (CausalWanModel._forward_inference + flow -> x0, sf_dit_forward).  Writes the new K/V rows
+    into k_cache / v_cache (and, with init_cross, the text K/V into ck_cache / cv_cache); returns (flow, x0), or two
+    empty tensors with cache_only."""
+    m = _model(model)
+    _need_gpu(noisy, "noisy")
+    _need_gpu(timestep, "timestep", None)
+    if noisy.dim() != 5 or not noisy.is_contiguous() or timestep.dim() != 2 or not timestep.is_contiguous():
+        raise ValueError("dit_forward: noisy must be contiguous [B, F, C, H, W], timestep contiguous [B, groups]")
+    if timestep.dtype not in (torch.float32, torch.int64):
+        raise ValueError(f"dit_forward: timestep must be float32 or int64, got {timestep.dtype}")
+    L = m.num_layers
+    if not (len(k_cache) == len(v_cache) == len(ck_cache) == len(cv_cache) == L):
+        raise ValueError(f"dit_forward: cache lists must have {L} entries")
+    B, F, _, H, W = noisy.shape
+    cap = k_cache[0].shape[1]
+    k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = _pointer_tables(model, k_cache, v_cache, ck_cache, cv_cache)
+    a = _lib.ForwardArgs()
+    a.batch, a.frames, a.lat_h, a.lat_w, a.groups = B, F, H, W, timestep.shape[1]
+    a.noisy, a.timestep = noisy.data_ptr(), timestep.data_ptr()
+    a.t_is_int64 = 1 if timestep.dtype == torch.int64 else 0
+    a.prompt_embeds = _ptr(prompt_embeds)
+    a.init_cross = 1 if init_cross else 0
+    a.add_condition = _ptr(add_condition)
+    a.k_cache_host, a.v_cache_host, a.ck_cache_host, a.cv_cache_host = k_ptrs, v_ptrs, ck_ptrs, cv_ptrs
+    a.cache_tokens = cap
+    a.sink_tokens, a.evict, a.keep = sink, evict, keep
+    a.write_start, a.attn_start, a.attn_end, a.start_frame = write_start, attn_start, attn_end, start_frame
+    if evict_scratch is not None:
+        a.evict_scratch, a.evict_scratch_bytes = evict_scratch.data_ptr(), evict_scratch.numel() * evict_scratch.element_size()
+    a.cache_only = 1 if cache_only else 0
+    if cache_only:
+        flow = torch.empty(0, dtype=torch.bfloat16, device=noisy.device)
+        x0 = torch.empty(0, dtype=torch.bfloat16, device=noisy.device)
+    else:
+        flow = torch.empty(B, F, m.shape.out_dim, H, W, dtype=torch.bfloat16, device=noisy.device)
+        x0 = torch.empty_like(flow)
+        a.flow_out, a.x0_out = flow.data_ptr(), x0.data_ptr()
+    a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    _lib.check(_lib.lib().sf_dit_forward(C.byref(m.cmodel), C.byref(a), _stream(noisy)), "sf_dit_forward")
+    return flow, x0
+
+
+@dit_forward.register_fake
+def _(model, noisy, timestep, prompt_embeds, add_condition, k_cache, v_cache, ck_cache, cv_cache, workspace, evict_scratch,
+      init_cross, cache_only, sink, evict, keep, write_start, attn_start, attn_end, start_frame):
+    if cache_only:
+        return noisy.new_empty((0,)), noisy.new_empty((0,))
+    B, F, _, H, W = noisy.shape
+    out_dim = _model(model).shape.out_dim
+    return noisy.new_empty((B, F, out_dim, H, W)), noisy.new_empty((B, F, out_dim, H, W))
+
+
+# ------------------------------------------------------------------------------------------ VAE decode / T5 encode
+@custom_op(f"{NAMESPACE}::vae_decode_frame", mutates_args=("state", "scratch", "out"))
+def vae_decode_frame(model: int, state: Tensor, scratch: Tensor, z: Tensor, out: Tensor, h: int, w: int, first: bool) -> None:
+    """One latent frame z [z_dim, h, w] -> 1 (first) or 4 pixel frames written to the front of `out` (float32
+    [T, 3, 8h, 8w]); `state` carries every convolution's two-frame history between calls (sf_vae_decode_frame)."""
+    m = _model(model)
+    _need_gpu(z, "z")
+    _need_gpu(out, "out", torch.float32)
+    if not z.is_contiguous() or not out.is_contiguous():
+        raise ValueError("vae_decode_frame: contiguous tensors expected")
+    _lib.check(_lib.lib().sf_vae_decode_frame(C.byref(m.cmodel), state.data_ptr(), state.numel(), scratch.data_ptr(), scratch.numel(),
+                                              z.data_ptr(), h, w, 1 if first else 0, out.data_ptr(), _stream(z)),
+               "sf_vae_decode_frame")
+
+
+@custom_op(f"{NAMESPACE}::t5_encode", mutates_args=("workspace",))
+def t5_encode(model: int, ids: Tensor, mask: Tensor, buckets: Tensor, workspace: Tensor) -> Tensor:
+    """umT5 encoder pass: ids, mask int64 [B, L] -> bf16 [B, L, dim], rows past each prompt's length zeroed (sf_t5_encode)."""
+    m = _model(model)
+    _need_gpu(ids, "ids", torch.int64), _need_gpu(mask, "mask", torch.int64), _need_gpu(buckets, "buckets", torch.int32)
+    if ids.dim() != 2 or ids.shape != mask.shape or not ids.is_contiguous() or not mask.is_contiguous():
+        raise ValueError("t5_encode: ids and mask must be contiguous [B, L]")
+    B, L = ids.shape
+    out = torch.empty(B, L, m.shape.dim, dtype=torch.bfloat16, device=ids.device)
+    _lib.check(_lib.lib().sf_t5_encode(C.byref(m.cmodel), ids.data_ptr(), mask.data_ptr(), buckets.data_ptr(), B, L, out.data_ptr(),
+                                       workspace.data_ptr(), workspace.numel(), _stream(ids)), "sf_t5_encode")
+    return out
+
+
+@t5_encode.register_fake
+def _(model, ids, mask, buckets, workspace):
+    return ids.new_empty((ids.shape[0], ids.shape[1], _model(model).shape.dim), dtype=torch.bfloat16)
+
+
+OPS = ("attention", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "vae_decode_frame", "t5_encode")

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, torch_ops
 from .vae_weights import (LATENT_MEAN, LATENT_STD, ResBlockSpec, ResampleSpec, VaeShape, WAN_VAE, decoder_layout,
                           vae_param_shapes)
 
@@ -125,6 +125,7 @@ class WanVAEDecoder:
         m.head_gamma = self._dev(sd["decoder.head.0.gamma"].flatten()).data_ptr()
         self._conv(m.head_conv, sd, "decoder.head.2")
         self.cmodel = m
+        self._handle = torch_ops.register_model(self)
 
     def param_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self._keep)
@@ -165,13 +166,10 @@ class WanVAEDecoder:
         state, scratch = self._buffers(h, w)
         sf, tf = self.shape.spatial_factor, self.shape.temporal_factor
         out = torch.empty(self.frames_out(F), 3, sf * h, sf * w, dtype=torch.float32, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
         t0 = 0
         for i in range(F):
             first = 1 if self._fresh else 0
-            _lib.check(_lib.lib().sf_vae_decode_frame(C.byref(self.cmodel), state.data_ptr(), state.numel(), scratch.data_ptr(),
-                                                      scratch.numel(), z[i].data_ptr(), h, w, first, out[t0:].data_ptr(), stream),
-                       "sf_vae_decode_frame")
+            torch.ops.sf_hip.vae_decode_frame(self._handle, state, scratch, z[i], out[t0:], h, w, bool(first))
             t0 += 1 if first else tf
             self._fresh = False
         return out
@@ -184,14 +182,25 @@ class WanVAEDecoder:
         return out
 
 
+VAE_CHECKPOINT = "wan_models/Wan2.1-T2V-1.3B/Wan2.1_VAE.pth"   # utils/wan_wrapper.py:74
+
+
 class WanVAEWrapper(torch.nn.Module):
     """Drop-in for the reference's `WanVAEWrapper` (utils/wan_wrapper.py:56-117), decode side.
 
     `state_dict`: the tensors of `Wan2.1_VAE.pth` (or the seeded stand-in of `vae_weights.synth_vae_state_dict`);
-    encoder tensors, if present, are ignored."""
+    encoder tensors, if present, are ignored.  Without one the reference's default checkpoint path is loaded
+    (weights-only); FileNotFoundError when it is absent."""
 
-    def __init__(self, state_dict: Dict[str, Tensor], device="cuda", shape: VaeShape = WAN_VAE):
+    def __init__(self, state_dict: Optional[Dict[str, Tensor]] = None, device="cuda", shape: VaeShape = WAN_VAE,
+                 checkpoint_path: str = VAE_CHECKPOINT):
         super().__init__()
+        if state_dict is None:   # `WanVAEWrapper()` as the reference's pipelines construct it (wan_wrapper.py:72-76)
+            import os
+            if not os.path.exists(checkpoint_path):
+                raise FileNotFoundError(f"VAE checkpoint {checkpoint_path!r} not found: download it as the reference's README "
+                                        "describes, or construct WanVAEWrapper(state_dict=...) / inject a vae= into the pipeline")
+            state_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         self.mean = torch.tensor(LATENT_MEAN, dtype=torch.float32)
         self.std = torch.tensor(LATENT_STD, dtype=torch.float32)
         self.model = WanVAEDecoder(shape, state_dict, device)

@@ -18,7 +18,6 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
-import ctypes as C
 import glob
 import os
 from typing import Dict, List, Optional
@@ -79,7 +78,6 @@ class WanDiffusionWrapper(torch.nn.Module):
         self.scheduler.set_timesteps(1000, training=True)
         self.model = CausalWanModel(shape, state_dict, device, self.scheduler.sigmas, self.scheduler.timesteps)
         self.seq_len = 32760
-        self._ptr_cache: Dict[int, tuple] = {}
         self._evict_scratch: Optional[Tensor] = None
 
     def share(self) -> "WanDiffusionWrapper":
@@ -91,7 +89,6 @@ class WanDiffusionWrapper(torch.nn.Module):
         other.scheduler = self.scheduler
         other.model = self.model
         other.seq_len = self.seq_len
-        other._ptr_cache = {}
         other._evict_scratch = None
         return other
 
@@ -131,19 +128,6 @@ class WanDiffusionWrapper(torch.nn.Module):
                 kv["global_end_index"].fill_(global_end)
                 kv["local_end_index"].fill_(local_end)
         d0["_sf_mirror"] = (d0["global_end_index"], d0["local_end_index"], global_end, local_end)
-
-    def _pointer_tables(self, kv_cache: List[dict], crossattn_cache: List[dict]):
-        L = self.model.num_layers
-        key = tuple(kv["k"].data_ptr() for kv in kv_cache) + tuple(c["k"].data_ptr() for c in crossattn_cache) + \
-            tuple(kv["v"].data_ptr() for kv in kv_cache) + tuple(c["v"].data_ptr() for c in crossattn_cache)
-        hit = self._ptr_cache.get("tables")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
-        tabs = (arr([kv["k"] for kv in kv_cache]), arr([kv["v"] for kv in kv_cache]),
-                arr([c["k"] for c in crossattn_cache]), arr([c["v"] for c in crossattn_cache]))
-        self._ptr_cache["tables"] = (key, tabs)
-        return tabs
 
     # --- the hot call --------------------------------------------------------------------------
     @torch.no_grad()
@@ -223,8 +207,8 @@ class WanDiffusionWrapper(torch.nn.Module):
                 raise ValueError(f"add_condition spatial dim {add_condition.shape[1]} doesn't match "
                                  f"x spatial dim {n_new}. Check pose data processing.")
             assert add_condition.shape[2] == mdl.cmodel.pose_dim, "add_condition channel width must match pose_proj"
-        k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = self._pointer_tables(kv_cache, crossattn_cache)
-        flow, x0 = mdl.forward(x, t, pe, init_cross, k_ptrs, v_ptrs, ck_ptrs, cv_ptrs, cap, plan,
+        flow, x0 = mdl.forward(x, t, pe, init_cross, [kv["k"] for kv in kv_cache], [kv["v"] for kv in kv_cache],
+                               [c["k"] for c in crossattn_cache], [c["v"] for c in crossattn_cache], plan,
                                current_start // fs, scratch, cache_only=cache_only, add_condition=add_condition)
         if init_cross:
             for c in crossattn_cache:

@@ -5,6 +5,7 @@ import os
 import re
 import subprocess
 import sys
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -370,3 +371,70 @@ def test_vae_wrapper_has_no_cpu_fallback():
         pytest.skip("CPU-only check")
     with pytest.raises((RuntimeError, AssertionError)):
         sfa.WanVAEWrapper(vw.synth_vae_state_dict(vw.VAE_REDUCED, seed=0), device="cuda:0", shape=vw.VAE_REDUCED)
+
+
+# -------------------------------------------------------------------------------- torch custom ops (row b')
+def test_torch_custom_ops_are_registered_with_mutation_schemas():
+    """torch.ops.sf_hip.* exist, take Tensors, and declare which arguments they write ("registered ... so
+    torch.ops.<ns>.* take Tensors"; the caches / workspace / outputs are the mutated ones)."""
+    for name in sfa.torch_ops.OPS:
+        assert hasattr(torch.ops.sf_hip, name), name
+    sch = {n: str(getattr(torch.ops.sf_hip, n).default._schema) for n in sfa.torch_ops.OPS}
+    assert "Tensor(a5!)[] k_cache" in sch["dit_forward"] and "Tensor(a6!)[] v_cache" in sch["dit_forward"]
+    assert "Tensor(a7!)[] ck_cache" in sch["dit_forward"] and "-> (Tensor, Tensor)" in sch["dit_forward"]
+    assert "Tensor(a1!) state" in sch["vae_decode_frame"] and "Tensor(a4!) out" in sch["vae_decode_frame"]
+    assert "Tensor(a0!) out" in sch["gemm_out"] and "Tensor(a0!) out" in sch["lincomb_out"]
+    assert "!" not in sch["attention"] and "!" not in sch["gemm"] and "!" not in sch["add_noise"]
+
+
+def test_torch_custom_ops_have_fake_implementations():
+    """Shape / dtype propagation without touching a GPU (what torch.compile's tracer runs, demo.py:340)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    class _Stub:                      # stands in for a device-resident model: the fake kernels only read its shape
+        shape = SimpleNamespace(out_dim=16, dim=4096)
+    stub = _Stub()
+    h = sfa.torch_ops.register_model(stub)
+    with FakeTensorMode():
+        e = lambda *s, dt=torch.bfloat16: torch.empty(*s, device="cuda", dtype=dt)  # noqa: E731
+        o = torch.ops.sf_hip.attention(e(2, 70, 3, 128), e(2, 300, 3, 128), e(2, 300, 3, 128))
+        assert tuple(o.shape) == (2, 70, 3, 128) and o.dtype == torch.bfloat16
+        y = torch.ops.sf_hip.gemm(e(100, 64), e(256, 64), e(256), 0, None, None, None, 1, 0)
+        assert tuple(y.shape) == (100, 256) and y.dtype == torch.bfloat16
+        y32 = torch.ops.sf_hip.gemm(e(100, 64), e(256, 64), None, 4, None, None, None, 1, 0)
+        assert y32.dtype == torch.float32
+        z = torch.ops.sf_hip.lincomb([e(3, 5), e(3, 5)], [0.5, 2.0])
+        assert tuple(z.shape) == (3, 5)
+        n = torch.ops.sf_hip.add_noise(e(3, 16, 8, 8), e(3, 16, 8, 8), e(3, dt=torch.float32), e(1000, dt=torch.float32), e(1000, dt=torch.float32))
+        assert tuple(n.shape) == (3, 16, 8, 8)
+        caches = [[e(1, 48, 4, 128) for _ in range(2)] for _ in range(2)] + [[e(1, 512, 4, 128) for _ in range(2)] for _ in range(2)]
+        flow, x0 = torch.ops.sf_hip.dit_forward(h, e(1, 2, 16, 8, 12), e(1, 2, dt=torch.float32), None, None, *caches,
+                                                e(1024, dt=torch.uint8), None, False, False, 0, 0, 0, 0, 0, 48, 0)
+        assert tuple(flow.shape) == (1, 2, 16, 8, 12) and tuple(x0.shape) == (1, 2, 16, 8, 12)
+        flow, x0 = torch.ops.sf_hip.dit_forward(h, e(1, 2, 16, 8, 12), e(1, 2, dt=torch.float32), None, None, *caches,
+                                                e(1024, dt=torch.uint8), None, False, True, 0, 0, 0, 0, 0, 48, 0)
+        assert flow.numel() == 0
+        t = torch.ops.sf_hip.t5_encode(h, e(2, 512, dt=torch.int64), e(2, 512, dt=torch.int64), e(1023, dt=torch.int32), e(64, dt=torch.uint8))
+        assert tuple(t.shape) == (2, 512, 4096) and t.dtype == torch.bfloat16
+
+
+def test_torch_custom_ops_refuse_cpu_tensors():
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="CUDA"):
+        torch.ops.sf_hip.gemm(x, x, None, 0, None, None, None, 1, 0)
+    with pytest.raises(ValueError, match="CUDA"):
+        torch.ops.sf_hip.lincomb([x], [1.0])
+    with pytest.raises(RuntimeError, match="not registered"):
+        torch.ops.sf_hip.t5_encode(12345, torch.zeros(1, 4, dtype=torch.int64), torch.zeros(1, 4, dtype=torch.int64),
+                                   torch.zeros(7, dtype=torch.int32), torch.zeros(8, dtype=torch.uint8))
+
+
+def test_default_components_need_the_reference_checkpoints(tmp_path, monkeypatch):
+    """`WanTextEncoder()` / `WanVAEWrapper()` -- what the pipelines build when nothing is injected
+    (causal_inference.py:19-23) -- load the reference's default local checkpoints and say so when they are absent."""
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError, match="umT5 checkpoint"):
+        sfa.WanTextEncoder(device="cpu")
+    with pytest.raises(FileNotFoundError, match="VAE checkpoint"):
+        sfa.WanVAEWrapper(device="cpu")
+    assert sfa.text_encoder.HuggingfaceTokenizer.clean("  a &amp;amp; b \n\t c ") == "a & b c"
