@@ -63,12 +63,16 @@ def usable_cores():
     return n
 
 
-def rollout_flops(shape, frames, nfpb, n_steps, fs, window_frames=0):
+def rollout_flops(shape, frames, nfpb, n_steps, fs, window_frames=0, executed=False):
     """Algorithmic FLOPs of one rollout: linear + cross-attn per token, self-attn
     4*C*N*Lk per layer per forward; (n_steps + 1) forwards per chunk.  `window_frames` > 0: rolling-window mode,
-    the keys a chunk attends to are capped at that many frames (causal_model.py:203-231)."""
+    the keys a chunk attends to are capped at that many frames (causal_model.py:203-231).
+    executed=True: what the HIP path really runs -- a chunk's context pass only updates the KV cache, so it returns
+    after the LAST layer's K/V write (sf_forward_args.cache_only) and skips that layer's self-attention, output
+    projection, cross-attention, FFN, and the head: nothing reads them (the reference computes and discards them)."""
     C, Fd, L = shape.dim, shape.ffn_dim, shape.num_layers
     per_tok = L * (12 * C * C + 4 * C * Fd + 4 * shape.text_len * C) + 2 * 64 * C + 2 * C * 64
+    skipped_per_tok = (6 * C * C + 4 * C * Fd + 4 * shape.text_len * C) + 2 * C * 64   # o, cross q/o, cross-attn, ffn; head
     total = 0.0
     n = nfpb * fs
     for chunk in range(frames // nfpb):
@@ -76,6 +80,8 @@ def rollout_flops(shape, frames, nfpb, n_steps, fs, window_frames=0):
         if window_frames > 0:
             lk = min(lk, window_frames * fs)
         total += (n_steps + 1) * (per_tok * n + L * 4.0 * C * n * lk)
+        if executed:
+            total -= skipped_per_tok * n + 4.0 * C * n * lk
     return total
 
 
@@ -110,16 +116,22 @@ def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
         flops.append(4.0 * shape.dim * n * lk)
     avg_ms = sum(durs) / len(durs)
     avg_flops = sum(flops) / len(flops)
-    traffic = None
-    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same shapes
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f)["attention_r64_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic = traffic_src = None
+    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same shapes -- a counter
+            # run cannot share a process with the timed one (profiled passes run at another clock), so this field is
+            # READ from the newest committed pass and labelled with its file
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                traffic = json.load(f)["attention_r64_kernel"]["hbm_bytes_per_launch"]
+            traffic_src = f"profiles/{cand} (committed rocprofv3 --pmc pass, not measured in this run)"
+            break
+        except (OSError, KeyError, ValueError):
+            pass
     att = {"bound": "mfma", "kernel": "attention_r64_kernel (self-attention over the KV cache)",
            "achieved": avg_flops / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the same 7 cache lengths)",
+           "traffic_source": traffic_src, "algorithmic_bytes_per_launch": 2 * (2 * n + 2 * sum(flops) / len(flops) / (4.0 * shape.dim * n)) * shape.dim,   # (Q + O + K + V) bf16
            "avg_launch_ms": avg_ms, "flops_per_launch": avg_flops,
            "per_lk_tflops": {str(min((i + 1) * n, lk_max)): flops[i] / (durs[i] * 1e-3) / 1e12 for i in range(len(durs))}}
     # GEMMs: ffn.0 (N = ffn_dim) and ffn.2 (K = ffn_dim) at M = n
@@ -136,6 +148,36 @@ def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
     gemm = {"ffn0_tflops": fl / (ms1 * 1e-3) / 1e12, "ffn2_tflops": fl / (ms2 * 1e-3) / 1e12,
             "ffn0_ms": ms1, "ffn2_ms": ms2, "M": n, "C": shape.dim, "ffn": shape.ffn_dim}
     return att, gemm
+
+
+def hbm_bound_leg(shape, dev, nfpb, fs):
+    """The HBM-bound kernels of a forward (reported as GB/s): algorithmic bytes per launch / mean launch
+    duration (events on the launch stream), against the 8 TB/s HBM3E peak.  Shapes of one S1 forward."""
+    HBM_PEAK = 8000.0
+    n, C, H = nfpb * fs, shape.dim, shape.num_heads
+    g = torch.Generator(device="cpu").manual_seed(2)
+    rb = lambda *s_: torch.randn(*s_, generator=g).to(torch.bfloat16).to(dev)  # noqa: E731
+    x, mod, e0 = rb(n, C), rb(6, C), rb(nfpb, 6 * C)
+    res = {}
+
+    def add(name, ms, nbytes, what):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        res[name] = {"GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK, "us": 1e3 * ms, "algorithmic_bytes": nbytes, "bytes": what}
+
+    ms = time_kernel(lambda: ops.layernorm_modulate(x, mod[0], mod[1], e0[:, :C], e0[:, C:2 * C], fs), 50)
+    add("layernorm_kernel (LN + AdaLN modulate)", ms, 2 * n * C * 2, "x read + y written")
+    qkv = rb(n, 3 * C)
+    kc = torch.zeros(1, n, H, 128, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    nq, nk = rb(C), rb(C)
+    from self_forcing_amd.model import rope_tables
+    cos, sin = (t.to(dev) for t in rope_tables(128))
+    ms = time_kernel(lambda: ops.qkv_norm_rope_cache(qkv, nq, nk, kc, vc, cos, sin, (nfpb, LAT_H // 2, LAT_W // 2), 0, 0), 50)
+    add("qkv_norm_rope_cache_kernel (QK-RMSNorm + RoPE + cache append)", ms, 6 * n * C * 2, "qkv read; q, K rows, V rows written")
+    xs, w6, b6 = rb(nfpb, C), rb(6 * C, C), rb(6 * C)
+    ms = time_kernel(lambda: ops.small_linear(xs, w6, b6, act_in="silu"), 50)
+    add("small_linear_kernel (time projection, M = 3)", ms, 6 * C * C * 2, "weights read once")
+    return res
 
 
 def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
@@ -162,11 +204,28 @@ def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
         dt = time.time() - t0
     # optimistic extrapolation: every one of the rollout's forwards costs what this empty-cache one does
     n_fwd = (total_frames // nfpb) * (n_steps + 1) * (nfpb / frames_sample)
-    fps = DECODED_PER_LATENT(total_frames) / (n_fwd * dt)
-    return {"value": fps, "unit": "decoded frames/s (upper bound, extrapolated)", "cores": cores, "kind": "port",
-            "sample": f"1 DiT forward, {frames_sample} latent frame(s) = {frames_sample * fs} tokens, empty KV cache, bf16, "
-                      f"{dt:.2f} s; rollout = {n_fwd:.0f} such forwards with growing cache (so the true CPU rate is lower)",
-            "forward_seconds": dt}
+    s1_fps = DECODED_PER_LATENT(total_frames) / (n_fwd * dt)
+    # MEASURED: BASELINE configs[0] ("T": configs/tiny_test.yaml + few-step keys) as a whole rollout of the oracle:
+    # independent first frame, 1 frame per block, shift 8, noise [1, 2, 16, 60, 104] = 2 chunks x (4 + 1) one-frame
+    # forwards of 1560 tokens; 5 decoded frames
+    Tn = torch.randn(1, 2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16)
+    eps = [torch.randn(1, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(6)]
+    targs = wo.RolloutArgs(num_frame_per_block=1, independent_first_frame=True, timestep_shift=8.0)
+    log("cpu_baseline: measured config-T rollout (10 one-frame forwards)")
+    with torch.no_grad():
+        t0 = time.time()
+        lat = wo.rollout(W, cfg, targs, Tn, pe, eps)
+        dt_T = time.time() - t0
+    assert torch.isfinite(lat.float()).all()
+    return {"value": DECODED_PER_LATENT(2) / dt_T, "unit": "decoded frames/s", "cores": cores, "kind": "port",
+            "sample": f"MEASURED: one whole config-T rollout of the CPU oracle (bf16, the reference's CPU path): 2 latent = 5 decoded "
+                      f"frames, 2 chunks x (4 + 1) forwards of {fs} tokens, {dt_T:.1f} s",
+            "rollout_seconds": dt_T,
+            "s1_extrapolated": {"value": s1_fps, "unit": "decoded frames/s (upper bound, extrapolated)",
+                                "sample": f"1 DiT forward, {frames_sample} latent frame(s) = {frames_sample * fs} tokens, empty KV cache, "
+                                          f"bf16, {dt:.2f} s; an S1 rollout = {n_fwd:.0f} such forwards with growing cache "
+                                          "(so the true CPU rate on S1 is lower)",
+                                "forward_seconds": dt}}
 
 
 def main():
@@ -265,6 +324,17 @@ def main():
     decoded = DECODED_PER_LATENT(a.frames)
     fps = world * a.steps * decoded / elapsed
     flops = rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window)
+    flops_exec = rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window, executed=True)
+    # one rollout ALONE on the GPU (one stream): the same step, nothing in flight beside it
+    one = None
+    if rank == 0 and a.streams > 1:
+        n_one = max(1, min(a.steps, 3))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_one):
+            one_step(pool.pipes[0], a.warmup + i % a.steps)
+        torch.cuda.synchronize()
+        one = (time.perf_counter() - t1) / n_one
     out = {
         "metric": "decoded frames/sec/node, Wan-1.3B 832x480 4-step AR rollout" if (a.model, LAT_H, LAT_W) == ("Wan2.1-T2V-1.3B", 60, 104)
                   else f"decoded frames/sec/node, {a.model} {8 * LAT_W}x{8 * LAT_H} 4-step AR rollout",
@@ -279,14 +349,22 @@ def main():
                    "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
                    "parallelism": f"prompt-sharded x{world}", "streams_per_gpu": a.streams},
         "algorithmic_tflop_per_step": flops / 1e12,
-        "achieved_tflops_per_gpu": flops * a.steps / elapsed / 1e12,
-        "mfma_frac_end_to_end": flops * a.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
+        "executed_tflop_per_step": flops_exec / 1e12,
+        "achieved_tflops_per_gpu": flops_exec * a.steps / elapsed / 1e12,
+        "mfma_frac_end_to_end": flops_exec * a.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
+        "flop_note": "algorithmic = the reference's (n_steps + 1) full forwards per chunk (SURVEY 8d); executed = minus what the "
+                     "context passes skip behind the last layer's K/V write (cache_only); achieved / frac divide EXECUTED work",
     }
+    if one is not None:
+        out["value_one_stream"] = decoded / one
+        out["ms_per_step_one_stream"] = 1e3 * one
+        out["achieved_tflops_one_stream"] = flops_exec / one / 1e12
     if rank == 0 and not a.no_roofline:
         log("roofline leg")
         att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs, window)
         out["roofline"] = att
         out["gemm"] = gemm
+        out["hbm_bound"] = hbm_bound_leg(shape, dev, nfpb, fs)
     if rank == 0 and not a.no_vae:
         # VAE decode: decode alone, then rollout + decode through the same pool
         log("vae decode leg")

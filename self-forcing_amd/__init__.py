@@ -7,7 +7,8 @@ There is no CPU or eager-PyTorch fallback: the compute entry points raise when t
 library has not been built.
 """
 from .weights import (WanShape, WAN_1_3B, WAN_14B, WAN_REDUCED, NAMED_SHAPES, synth_state_dict,  # noqa: F401
-                      param_shapes, merge_lora, strip_prefix)
+                      param_shapes, merge_lora, strip_prefix, synth_lora_state_dict, apply_lora_file,
+                      load_lora_file, lora_target_linears)
 from .kvcache import CachePlan, plan_cache_update  # noqa: F401
 from .scheduler import FlowMatchScheduler  # noqa: F401
 from .wan_wrapper import WanDiffusionWrapper  # noqa: F401
@@ -24,7 +25,8 @@ from .unipc import FlowUniPCMultistepScheduler  # noqa: F401
 from . import ops, _lib, torch_ops, text_encoder  # noqa: F401
 
 __all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict",
-           "param_shapes", "merge_lora", "strip_prefix", "CachePlan", "plan_cache_update",
+           "param_shapes", "merge_lora", "strip_prefix", "synth_lora_state_dict", "apply_lora_file", "load_lora_file",
+           "lora_target_linears", "CachePlan", "plan_cache_update",
            "FlowMatchScheduler", "WanDiffusionWrapper", "CausalInferencePipeline",
            "SyntheticTextEncoder", "FixedTextEncoder", "IdentityVAE", "RolloutPool", "ops", "torch_ops",
            "VaeShape", "WAN_VAE", "VAE_REDUCED", "synth_vae_state_dict", "vae_param_shapes", "WanVAEWrapper",

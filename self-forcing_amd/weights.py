@@ -169,3 +169,100 @@ def merge_lora(sd: Dict[str, Tensor], alpha: float, rank: int) -> Dict[str, Tens
         else:
             out[k] = v
     return out
+
+
+# ------------------------------------------------------------------------------------------ LoRA files
+LORA_DEFAULT_TARGETS = ("q", "k", "v", "o")        # utils/wan_wrapper.py:147
+_LORA_PREFIXES = ("diffusion_model.", "model.", "pipe.dit.", "pipe.")     # utils/lora.py:97, :179
+
+
+def lora_target_linears(s: WanShape, targets: Iterable[str] = LORA_DEFAULT_TARGETS):
+    """Names of the Linears `apply_lora(model, target_modules=targets)` wraps (utils/lora.py:106-140): the attribute
+    names in `targets` on BOTH attentions of every block (cross-attention subclasses the self-attention class), and
+    `ffn.<idx>` entries on the block's feed-forward Sequential."""
+    names = []
+    attn = [t for t in targets if not t.startswith("ffn.")]
+    ffn = [t for t in targets if t.startswith("ffn.") and t.split(".", 1)[1].isdigit()]
+    for i in range(s.num_layers):
+        for a in ("self_attn", "cross_attn"):
+            names += [f"blocks.{i}.{a}.{t}" for t in attn if t in ("q", "k", "v", "o")]
+        names += [f"blocks.{i}.{t}" for t in ffn if t in ("ffn.0", "ffn.2")]
+    return names
+
+
+def synth_lora_state_dict(s: WanShape, rank: int, seed: int = 0, targets: Iterable[str] = LORA_DEFAULT_TARGETS,
+                          b_std: float = 0.05, dtype=torch.bfloat16, prefix: str = "") -> Dict[str, Tensor]:
+    """Seeded NON-ZERO adapters for the parity tests, in the reference's key layout (`<linear>.lora_A.weight`
+    [rank, in], `<linear>.lora_B.weight` [out, rank]).  A follows LoRALinear's init (kaiming_uniform(a=sqrt(5)) =
+    U(-1/sqrt(in), 1/sqrt(in)), utils/lora.py:32); B ~ N(0, b_std) instead of the reference's zeros (:33), which would
+    make every LoRA test vacuous."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shapes = param_shapes(s)
+    sd: Dict[str, Tensor] = {}
+    for name in lora_target_linears(s, targets):
+        out_f, in_f = shapes[name + ".weight"]
+        bound = 1.0 / math.sqrt(in_f)
+        sd[f"{prefix}{name}.lora_A.weight"] = torch.empty(rank, in_f).uniform_(-bound, bound, generator=g).to(dtype)
+        sd[f"{prefix}{name}.lora_B.weight"] = (b_std * torch.randn(out_f, rank, generator=g)).to(dtype)
+    return sd
+
+
+def load_lora_file(path: str) -> Dict[str, Tensor]:
+    """`.safetensors`, or a torch checkpoint read with weights_only=True (utils/lora.py:53-61)."""
+    if str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(str(path))
+    return torch.load(str(path), map_location="cpu", weights_only=True)
+
+
+def apply_lora_file(sd: Dict[str, Tensor], lora_sd: Dict[str, Tensor], s: WanShape, rank: int, alpha: float,
+                    targets: Iterable[str] = LORA_DEFAULT_TARGETS):
+    """What `apply_lora` + `load_lora_weights` (utils/lora.py:100-234) amount to at inference, with the adapters folded
+    into the base matrices: for every (lora_B | lora_up, lora_A | lora_down) pair of the file whose target -- after
+    dropping an optional `.default`, a known prefix and a trailing `.weight` -- is one of the wrapped Linears,
+    W += (alpha / rank) * up @ down.  `rank` is the CONSTRUCTOR's rank, as in the reference (`module.scaling =
+    alpha / module.rank`, :228-230), not the file's.  Pairs for other modules are skipped, as the reference skips them.
+    Returns (state dict, loaded, skipped)."""
+    wrapped = set(lora_target_linears(s, targets))
+    out = dict(sd)
+    loaded = skipped = 0
+    scale = alpha / rank
+    for key_up in lora_sd:
+        if "lora_B" in key_up:
+            key_down = key_up.replace("lora_B", "lora_A")
+        elif "lora_up" in key_up:
+            key_down = key_up.replace("lora_up", "lora_down")
+        else:
+            continue
+        if key_down not in lora_sd:
+            continue
+        parts = key_up.split(".")
+        tok = "lora_B" if "lora_B" in parts else "lora_up" if "lora_up" in parts else None
+        if tok is None:
+            skipped += 1
+            continue
+        i = parts.index(tok)
+        parts.pop(i)
+        if i < len(parts) and parts[i] == "default":
+            parts.pop(i)
+        target = ".".join(parts)
+        for pre in _LORA_PREFIXES:
+            if target.startswith(pre):
+                target = target[len(pre):]
+                break
+        if target.endswith(".weight") or target.endswith(".bias"):
+            target = target.rsplit(".", 1)[0]
+        if target.endswith(".base"):
+            target = target[:-5]
+        if target not in wrapped or target + ".weight" not in out:
+            skipped += 1
+            continue
+        up, down = lora_sd[key_up].float(), lora_sd[key_down].float()
+        W = out[target + ".weight"]
+        if up.shape[0] != W.shape[0] or down.shape[1] != W.shape[1] or up.shape[1] != down.shape[0]:
+            raise ValueError(f"LoRA pair for {target}: up {tuple(up.shape)} / down {tuple(down.shape)} do not fit weight {tuple(W.shape)}")
+        # the reference copies the file's tensors into the adapters in the MODEL's dtype (bf16) before use (:223-227)
+        up, down = up.to(W.dtype).float(), down.to(W.dtype).float()
+        out[target + ".weight"] = (W.float() + scale * (up @ down)).to(W.dtype)
+        loaded += 1
+    return out, loaded, skipped
