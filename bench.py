@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--cfg-frames", type=int, default=6,
                     help="latent frames of the 50-step CFG sampler leg (SURVEY 8f-4); 0 skips it, 21 = the whole clip (~20 s)")
     ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
+    ap.add_argument("--batch", type=int, default=1, help="prompts per rollout call (batch dimension of every kernel)")
     a = ap.parse_args()
     LAT_H, LAT_W = a.latent_height, a.latent_width
 
@@ -285,15 +286,16 @@ def main():
         assert lo.item() == hi.item(), "weight replicas differ across ranks"
 
     total = a.warmup + a.steps
-    idx = shard_indices(total * world, rank, world)             # rank r: r, r + W, r + 2W, ...
+    B = a.batch
+    idx = shard_indices(total * world * B, rank, world)         # rank r: r, r + W, r + 2W, ...
     prompts = [f"synthetic MovieGenVideoBench prompt #{i}" for i in idx]
-    for p in prompts:
-        enc([p])                                                # embeddings resident in HBM before timing
+    for i in range(total):
+        enc(prompts[B * i:B * i + B])                           # embeddings resident in HBM before timing
     torch.manual_seed(0 + rank)                                 # set_seed(seed + rank), inference.py:45
 
     def one_step(pipe, i):
-        noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
-        return pipe.inference(noise, [prompts[i]], return_latents=True, profile=a.profile and rank == 0)[1]
+        noise = torch.randn([B, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
+        return pipe.inference(noise, prompts[B * i:B * i + B], return_latents=True, profile=a.profile and rank == 0)[1]
 
     log(f"model resident ({gen.model.param_bytes() / 1e9:.2f} GB); warmup x{a.warmup}, {a.streams} stream(s)")
     tw = time.perf_counter()
@@ -321,13 +323,13 @@ def main():
     lat = lats[-1]
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
 
-    decoded = DECODED_PER_LATENT(a.frames)
+    decoded = DECODED_PER_LATENT(a.frames) * B                  # per step (= per rollout call)
     fps = world * a.steps * decoded / elapsed
-    flops = rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window)
-    flops_exec = rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window, executed=True)
+    flops = B * rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window)
+    flops_exec = B * rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window, executed=True)
     # one rollout ALONE on the GPU (one stream): the same step, nothing in flight beside it
     one = None
-    if rank == 0 and a.streams > 1:
+    if rank == 0 and (a.streams > 1 or B > 1) and B == 1:
         n_one = max(1, min(a.steps, 3))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -344,10 +346,10 @@ def main():
         "config": {"workload": f"S1: {a.model}-shape random-init weights, latent {a.frames}x16x{LAT_H}x{LAT_W} "
                                f"({decoded} decoded frames), {nfpb} frames/chunk, steps {step_list} warped (shift {shift}) "
                                f"+ 1 context pass per chunk, " + (f"rolling KV window of {window} frames (sink {a.sink_size}), " if window else "")
-                               + f"batch 1 per rollout, {a.streams} rollout(s) in flight per GPU "
+                               + f"batch {B} per rollout, {a.streams} rollout(s) in flight per GPU "
                                f"(one HIP stream each, shared weights), prompts sharded rank::N",
                    "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
-                   "parallelism": f"prompt-sharded x{world}", "streams_per_gpu": a.streams},
+                   "parallelism": f"prompt-sharded x{world}", "streams_per_gpu": a.streams, "batch_per_rollout": B},
         "algorithmic_tflop_per_step": flops / 1e12,
         "executed_tflop_per_step": flops_exec / 1e12,
         "achieved_tflops_per_gpu": flops_exec * a.steps / elapsed / 1e12,

@@ -444,6 +444,212 @@ __global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Ping-pong structure ("pp"): (32 MT) x 256 output tile per 512-thread workgroup, 8 waves as 2 (M) x 4 (N), one
+// workgroup per CU.  The two waves that share a SIMD (wave w and w + 4: the two M halves) run ONE BARRIER INTERVAL
+// APART: while one issues its MFMA cluster (a quarter of its sub-tile x one 64-deep k-tile, from registers) the other
+// reads its next fragments from LDS and requests LDS-DMA pieces -- the matrix pipe of every SIMD always has a cluster to
+// run, and neither wave's LDS / address work sits in front of its own MFMAs.  The kernels above run both waves of a
+// SIMD in lockstep (MFMAs together, loads together) and drain the LDS-DMA (vmcnt(0)) once per k-tile; here the
+// requests stay in flight across barriers and are waited for ONCE per k-tile with a counted vmcnt that leaves the
+// youngest two half-tiles outstanding (raw s_barrier: __syncthreads() would drain them).
+//
+// Per k-tile t (4 phases j = 0..3; buffer t & 1; A fragments of the current row half + B fragments of all four
+// column tiles live in registers):
+//     phase   fragments read from LDS (tile t)        cluster                LDS-DMA requested
+//     j = 0   A rows q0 (MT/2 tiles), B cols 0,1      (q0, cols 0,1)         A half 0 of tile t+1
+//     j = 1   B cols 2,3                              (q0, cols 2,3)         A half 1 of tile t+1
+//     j = 2   A rows q1                               (q1, cols 2,3)         B half 0 of tile t+2
+//     j = 3   --                                      (q1, cols 0,1)         B half 1 of tile t+2; vmcnt(4)
+// Write-after-read: B of tile t is in registers after j = 1, A half h after j = 2, and every read is retired
+// (lgkmcnt(0)) before the barrier that ends its interval, so the regions are free when the requests above are issued
+// (A(t+1) goes to the OTHER buffer, last read during tile t-1).  Read-after-write: tile t+1's first reads come after
+// the barrier behind the vmcnt(4) of phase (t, 3), executed by every wave: everything but B(t+2) has landed.
+constexpr int PP_THREADS = 512;
+
+template <int MT>   // M tiles of 16 rows per wave: 8 (256-row workgroup tile) or 4 (128-row)
+struct PPCfg {
+  static constexpr int BM = 32 * MT;
+  static constexpr int A_BYTES = BM * 128;          // one k-tile of A: BM rows x 64 bf16
+  static constexpr int B_BYTES = 256 * 128;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int LDS = 2 * STAGE;             // 128 KiB (MT = 8) / 96 KiB (MT = 4)
+  static constexpr int PA = MT / 4;                 // LDS-DMA pieces (8 rows x 128 B) per wave per A half-tile
+};
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
+  using Cfg = PPCfg<MT>;
+  constexpr int BMp = Cfg::BM, PA = Cfg::PA, HQ = MT / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;          // grp: M half of the tile = which of the two staggered wave groups
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GROUP_M = MT == 8 ? 4 : 8;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = wg / width, first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * width;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int m0 = tm * BMp, n0 = tn * 256;
+
+  // ---- LDS-DMA source addresses: a piece = 8 rows x 128 B; half-tile h of A = rows [h BM/2, (h+1) BM/2), of B =
+  // rows (= output columns) [128 h, 128 h + 128); wave w requests pieces w (+ 8 i) of every half-tile.
+  const bf16_t* a_src[2][PA];
+  const bf16_t* w_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int r = h * (BMp / 2) + (wave + 8 * i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      a_src[h][i] = p.a + (long)min(m0 + r, p.M - 1) * p.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = h * 128 + (wave + 8 * i) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      w_src[h][i] = p.w + (long)min(n0 + r, p.N - 1) * p.ldw + c * 8;
+    }
+  }
+  auto dma_a = [&](int h, int kt) {
+    char* base = smem + (kt & 1) * Cfg::STAGE + h * (Cfg::A_BYTES / 2) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(a_src[h][i] + kt * BK, base + i * 8192);
+  };
+  auto dma_b = [&](int h, int kt) {
+    char* base = smem + (kt & 1) * Cfg::STAGE + Cfg::A_BYTES + h * (Cfg::B_BYTES / 2) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(w_src[h][i] + kt * BK, base + i * 8192);
+  };
+
+  // ---- fragment read addresses (16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7))
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int swz = (i16 >> 1) & 7;
+  const int x_row_off = (grp * (BMp / 2) + i16) * 128;               // + 2048 per M tile
+  const int w_row_off = Cfg::A_BYTES + (wc * 64 + i16) * 128;        // + 2048 per N tile
+  const int coff[2] = {((0 + kq) ^ swz) << 4, ((4 + kq) ^ swz) << 4};
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[HQ][2], bfr[4][2];
+
+  const int nk = p.K / BK;
+  // prologue: A(0), B(0), then B(1) which may still be in flight when tile 0 starts (same count as in the loop)
+  dma_a(0, 0); dma_a(1, 0); dma_b(0, 0); dma_b(1, 0);
+  if (nk > 1) { dma_b(0, 1); dma_b(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();       // the second wave group runs one interval behind the first
+
+  auto end_load_segment = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's fragment reads are retired
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto cluster = [&](int q, int c0) {               // MT/2 row tiles x 2 column tiles x 2 sub-steps of 32
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < HQ; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[q * HQ + mt][c0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c0 + nt][ks], af[mt][ks], acc[q * HQ + mt][c0 + nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto read_a = [&](const char* buf, int q) {
+#pragma unroll
+    for (int mt = 0; mt < HQ; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + (q * HQ + mt) * 2048 + coff[ks]);
+  };
+  auto read_b = [&](const char* buf, int c0) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        bfr[c0 + nt][ks] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + (c0 + nt) * 2048 + coff[ks]);
+  };
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* buf = smem + (kt & 1) * Cfg::STAGE;
+    const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+    // phase 0
+    read_a(buf, 0);
+    read_b(buf, 0);
+    if (more1) dma_a(0, kt + 1);
+    end_load_segment();
+    cluster(0, 0);
+    // phase 1
+    read_b(buf, 2);
+    if (more1) dma_a(1, kt + 1);
+    end_load_segment();
+    cluster(0, 2);
+    // phase 2
+    read_a(buf, 1);
+    if (more2) dma_b(0, kt + 2);
+    end_load_segment();
+    cluster(1, 2);
+    // phase 3: everything but the two half-tiles of B(kt + 2) must have landed before the next tile's first reads
+    if (more2) {
+      dma_b(1, kt + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    end_load_segment();
+    cluster(1, 0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with the extra barrier of the second group: all clusters done
+
+  // ---- epilogue (no LDS-DMA is in flight, every fragment read is retired: the stages are free)
+  const int m_base = m0 + grp * (BMp / 2), n_base = n0 + wc * 64;
+  if ((p.N & 7) == 0 && (p.ldo & 7) == 0)
+    gemm_epilogue_lds<EPI, MT>(p, acc, m_base, n_base, smem + wave * (MT * 2048), lane);
+  else
+    gemm_epilogue<EPI, MT>(p, acc, m_base + (lane & 15), n_base + (lane >> 4) * 4);
+}
+
+template <int EPI, int MT>
+int launch_pp(GemmP& p, hipStream_t s) {
+  using Cfg = PPCfg<MT>;
+  static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent)
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    attr = true;
+  }
+  p.tiles_m = (p.M + Cfg::BM - 1) / Cfg::BM;
+  p.tiles_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm_pp_kernel<EPI, MT>), dim3(p.tiles_m * p.tiles_n), dim3(PP_THREADS), Cfg::LDS, s, p);
+  return 0;
+}
+
+template <int MT>
+int launch_pp_epi(GemmP& p, int epilogue, hipStream_t s) {
+  switch (epilogue) {
+    case SF_EPI_BIAS: return launch_pp<SF_EPI_BIAS, MT>(p, s);
+    case SF_EPI_BIAS_GELU: return launch_pp<SF_EPI_BIAS_GELU, MT>(p, s);
+    case SF_EPI_BIAS_RESID: return launch_pp<SF_EPI_BIAS_RESID, MT>(p, s);
+    case SF_EPI_BIAS_GATE_RESID: return launch_pp<SF_EPI_BIAS_GATE_RESID, MT>(p, s);
+    default: return -1;
+  }
+}
+
 template <int EPI>
 int launch_big(GemmP& p, hipStream_t s) {
   static bool attr = false;
@@ -485,15 +691,31 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
   p.tiles_n = (a->N + BN - 1) / BN;
   hipStream_t s = (hipStream_t)stream;
   p.tiles_m = (a->M + BM - 1) / BM;
-  // wide outputs whose 256 x 256 tiles fill the chip in nearly whole rounds take the large-tile structure
-  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_T256, "sf_gemm_bf16: unknown structure %d", a->structure);
+  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_PP128, "sf_gemm_bf16: unknown structure %d", a->structure);
   {
-    const long tb = (long)((a->M + BBM - 1) / BBM) * ((a->N + BBN - 1) / BBN);
-    const long rounds = (tb + 255) / 256;
-    bool big = a->N >= 2048 && a->M >= 1024 && tb >= 512 && (double)tb / (rounds * 256) >= 0.8;
-    if (a->structure != SF_GEMM_AUTO) big = a->structure == SF_GEMM_T256;
-    if (a->batch > 1) big = false;
-    if (big && a->epilogue != SF_EPI_F32) {
+    int st = a->structure;
+    const bool pp_ok = a->batch <= 1 && a->epilogue != SF_EPI_F32 && a->K >= 2 * BK;
+    if (st == SF_GEMM_AUTO) {
+      // Large problems take the ping-pong structure; its row tile (256 or 128) is the one whose tile count wastes less
+      // of the chip's 256 workgroup slots (one workgroup per CU).  Everything else: 128 x 128 tiles, two per CU.
+      st = SF_GEMM_T128;
+      if (pp_ok && a->M >= 1024 && a->N >= 1024 && a->K >= 512) {
+        const long tn = (a->N + 255) / 256;
+        const long t256 = (long)((a->M + 255) / 256) * tn, t128 = (long)((a->M + 127) / 128) * tn;
+        const double e256 = (double)a->M * a->N / (((t256 + 255) / 256) * 256.0 * 256 * 256);
+        const double e128 = (double)a->M * a->N / (((t128 + 255) / 256) * 256.0 * 128 * 256) * 0.93;   // smaller register tile
+        st = e256 >= e128 ? SF_GEMM_PP256 : SF_GEMM_PP128;
+      }
+    }
+    if ((st == SF_GEMM_PP256 || st == SF_GEMM_PP128) && !pp_ok) st = SF_GEMM_T128;
+    if (st == SF_GEMM_T256 && (a->batch > 1 || a->epilogue == SF_EPI_F32)) st = SF_GEMM_T128;
+    if (st == SF_GEMM_PP256 || st == SF_GEMM_PP128) {
+      const int rc = st == SF_GEMM_PP256 ? launch_pp_epi<8>(p, a->epilogue, s) : launch_pp_epi<4>(p, a->epilogue, s);
+      SF_CHECK(rc == 0, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
+      SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
+      return 0;
+    }
+    if (st == SF_GEMM_T256) {
       switch (a->epilogue) {
         case SF_EPI_BIAS: launch_big<SF_EPI_BIAS>(p, s); break;
         case SF_EPI_BIAS_GELU: launch_big<SF_EPI_BIAS_GELU>(p, s); break;

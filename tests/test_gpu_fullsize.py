@@ -382,9 +382,10 @@ def test_kv_cache_near_hbm_capacity_batch10(sd_1p3b):
 def test_14b_720p_forward_vs_oracle():
     """BASELINE configs[4] at its real token count: Wan-14B layer geometry (dim 5120, 40 heads of 128, ffn 13824) on a
     720p latent [16, 3, 90, 160] = 3 x 3600 = 10800 tokens per chunk (42 x 256 + 48: ragged 256-row tiles in every GEMM
-    and in attention), two forwards (the second against a cache of 21600 tokens), 2 of the 40 layers (the fp32 CPU
-    oracle needs ~1 minute per layer pair), against the fp32 oracle -- which reproduces the reference to 2e-7 at the
-    1.3B shape; the reference pipeline itself cannot run this shape (hard-coded 1560 tokens / 30 layers / 12 heads)."""
+    and in attention), one forward, 2 of the 40 layers (the fp32 CPU oracle needs over a minute for these two), against
+    the fp32 oracle -- which reproduces the reference to 2e-7 at the 1.3B shape; the reference pipeline itself cannot
+    run this shape (hard-coded 1560 tokens / 30 layers / 12 heads).  The append to a 21600-token cache at this shape is
+    covered by the attention test at (40 heads, Lq 10800, Lk 21600)."""
     shape = sfa.WanShape(dim=5120, ffn_dim=13824, num_heads=40, num_layers=2)
     sd = sfa.synth_state_dict(shape, seed=5)
     g = torch.Generator().manual_seed(6)
@@ -392,27 +393,22 @@ def test_14b_720p_forward_vs_oracle():
     fs = (H // 2) * (W // 2)
     assert fs == 3600
     x1 = torch.randn(1, F, 16, H, W, generator=g).to(torch.bfloat16)
-    x2 = torch.randn(1, F, 16, H, W, generator=g).to(torch.bfloat16)
     pe = torch.randn(1, 512, shape.text_dim, generator=g).to(torch.bfloat16)
     pe[:, 133:] = 0
-    t1 = torch.tensor([[937.5, 937.5, 937.5]])
-    t2 = torch.tensor([[625.0, 625.0, 625.0]])
+    t1 = torch.tensor([[937.5, 833.3333129882812, 625.0]])
     gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=5.0, is_causal=True, device=DEV)
     pipe = sfa.CausalInferencePipeline(_args(3), DEV, generator=gen, text_encoder=sfa.FixedTextEncoder(pe.to(DEV)), vae=sfa.IdentityVAE())
     pipe.frame_seq_length = fs
-    pipe._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=2 * F * fs)
+    pipe._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=F * fs)
     pipe._initialize_crossattn_cache(1, torch.bfloat16, DEV)
     cond = {"prompt_embeds": pe.to(DEV)}
-    f1, _ = gen(x1.to(DEV), cond, t1.to(DEV), pipe.kv_cache1, pipe.crossattn_cache, 0)
-    f2, z2 = gen(x2.to(DEV), cond, t2.to(DEV), pipe.kv_cache1, pipe.crossattn_cache, F * fs)
+    f1, z1 = gen(x1.to(DEV), cond, t1.to(DEV), pipe.kv_cache1, pipe.crossattn_cache, 0)
     torch.cuda.synchronize()
     Wf = wo.prepare_weights(sd, torch.float32)
     cfg = wo.OracleConfig(dim=shape.dim, ffn_dim=shape.ffn_dim, num_heads=shape.num_heads, num_layers=shape.num_layers)
-    kv, ca = wo.init_kv_cache(cfg, 1, 2 * F * fs, torch.float32), wo.init_crossattn_cache(cfg, 1, torch.float32)
-    tab = wo.FlowMatchTables(5.0)
-    r1, _ = wo.wrapper_forward(Wf, cfg, tab, x1.float(), pe.float(), t1, kv, ca, 0)
-    r2, rz2 = wo.wrapper_forward(Wf, cfg, tab, x2.float(), pe.float(), t2, kv, ca, F * fs)
-    assert rel(f1, r1) < 2e-2 and rel(f2, r2) < 2e-2 and rel(z2, rz2) < 2e-2, (rel(f1, r1), rel(f2, r2))
+    kv, ca = wo.init_kv_cache(cfg, 1, F * fs, torch.float32), wo.init_crossattn_cache(cfg, 1, torch.float32)
+    r1, rz1 = wo.wrapper_forward(Wf, cfg, wo.FlowMatchTables(5.0), x1.float(), pe.float(), t1, kv, ca, 0)
+    assert rel(f1, r1) < 2e-2 and rel(z1, rz1) < 2e-2, (rel(f1, r1), rel(z1, rz1))
     for f in range(F):     # frame by frame (the last frame ends in the ragged tiles)
-        assert rel(f2[:, f], r2[:, f]) < 2e-2, f
+        assert rel(f1[:, f], r1[:, f]) < 2e-2, f
     assert rel(pipe.kv_cache1[1]["k"], kv[1]["k"]) < 2e-2 and rel(pipe.kv_cache1[1]["v"], kv[1]["v"]) < 2e-2

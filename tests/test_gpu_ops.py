@@ -132,6 +132,60 @@ def test_gemm_large_tile_structure(epi):
     assert rel(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("structure", ["t128", "t256", "pp256", "pp128"])
+@pytest.mark.parametrize("M,N,K,epi", [(4680, 1536, 1536, "gate_resid"), (4680, 4608, 1536, "bias"), (1560, 8960, 1536, "gelu"),
+                                       (4680, 1536, 8960, "gate_resid"), (10800, 5120, 5120, "resid"), (1100, 1288, 128, "gelu"),
+                                       (257, 264, 192, "resid"), (3000, 1024, 64, "bias")])
+def test_gemm_every_structure(structure, M, N, K, epi):
+    """Every tiling on the rollout's own GEMM shapes (qkv, the N = 1536 projections, ffn.0, ffn.2 with its 140 k-tiles,
+    a 14B / 720p projection) and on ragged ones: rows not a multiple of 16, N not a multiple of the 256 / 128 tile,
+    2 and 3 k-tiles (the ping-pong structure's prologue and tail), K = 64 (falls back to the 128 x 128 kernel).
+    All structures must also agree with each other to the last bit: same MFMA, same k order, same epilogue."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias, resid = bf((M, K), g), bf((N, K), g, 1.0 / K ** 0.5), bf((N,), g, 0.5), bf((M, N), g)
+    groups = 3 if M % 3 == 0 else 1
+    gate_mod, e0 = bf((N,), g, 0.5), bf((groups, 6, N), g, 0.5)
+    y = a.float() @ w.float().t() + bias.float()
+    kw = {}
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(y, approximate="tanh")
+    elif epi == "resid":
+        ref, kw = resid.float() + y, {"resid": resid.to(DEV)}
+    elif epi == "gate_resid":
+        gate = (gate_mod.float()[None] + e0[:, 5].float()).to(torch.bfloat16).float()
+        ref = resid.float() + y * gate.repeat_interleave(M // groups, dim=0)
+        kw = dict(resid=resid.to(DEV), gate_mod=gate_mod.to(DEV), gate_e0=e0.to(DEV)[:, 5], rows_per_group=M // groups)
+    else:
+        ref = y
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    out = ops.gemm(ad, wd, bd, epilogue=epi, structure=structure, **kw)
+    assert rel(out, ref) < 4e-3
+    assert torch.equal(out, ops.gemm(ad, wd, bd, epilogue=epi, structure="t128", **kw))
+    assert torch.equal(out, ops.gemm(ad, wd, bd, epilogue=epi, **kw))          # the automatic choice
+
+
+def test_gemm_pingpong_is_race_free_under_repetition():
+    """The ping-pong structure keeps LDS-DMA requests in flight across barriers (counted vmcnt): an early fragment
+    read or a late buffer reuse would show as rare wrong tiles that come and go with timing.  200 launches of two
+    shapes (many k-tiles; few k-tiles + many workgroup rounds), beside a second stream that keeps the memory system
+    busy, every result compared bit for bit with the first."""
+    g = torch.Generator().manual_seed(5)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.bfloat16, device=DEV)
+    for (M, N, K, st) in [(4680, 1536, 8960, "pp128"), (4680, 8960, 1536, "pp256"), (4680, 4608, 1536, "pp128"), (2048, 2048, 2048, "pp256")]:
+        a, w = bf((M, K), g).to(DEV), bf((N, K), g, 1.0 / K ** 0.5).to(DEV)
+        first = ops.gemm(a, w, None, structure=st)
+        assert rel(first, a.float().cpu() @ w.float().cpu().t()) < 4e-3
+        bad = 0
+        for i in range(50):
+            if i % 5 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            bad += int(not torch.equal(ops.gemm(a, w, None, structure=st), first))
+        torch.cuda.synchronize()
+        assert bad == 0, (M, N, K, st, bad)
+
+
 # ----------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 32, 64), (1, 2, 100, 200), (2, 3, 130, 24), (1, 4, 24, 512),
                                         (1, 2, 1560, 4680), (1, 1, 200, 1561)])
@@ -235,7 +289,10 @@ def test_attention_r64_long_sequences_vs_fp32(H, Lq, Lk, kind):
     assert torch.isfinite(out.float()).all()
     got = out[:, rows.to(DEV)].float().cpu()
     assert rel(got, ref) < 6e-3, rel(got, ref)
-    assert (got - ref).abs().max() < 0.05 * max(ref.pow(2).mean().sqrt().item(), 0.2)
+    # element-wise: bf16 rounding of the output (2^-9 relative: rows dominated by one aligned key hold O(1) values) plus
+    # a floor scaled to the output's rms (long sequences average thousands of V rows: rms ~ 0.05 ... 0.1)
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((got - ref).abs() <= 1.2e-2 * ref.abs() + 0.05 * rms).all(), ((got - ref).abs().max().item(), rms)
     # per head as well: one bad head among 40 would hide in the overall norm
     for h in range(H):
         assert rel(got[:, :, h], ref[:, :, h]) < 8e-3, h

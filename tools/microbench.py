@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--lk", default="4680,18720,32760")
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--vae-frames", type=int, default=21)
+    ap.add_argument("--structures", default="auto", help="GEMM tilings to time, e.g. auto,t128,t256,pp256,pp128")
+    ap.add_argument("--rounds", type=int, default=1, help="interleaved timing rounds per (shape, structure); the best is printed")
     a = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(0)
@@ -57,8 +59,14 @@ def main():
             r = torch.zeros(a.n, N, dtype=torch.bfloat16, device=dev)
             o = torch.empty(a.n, N, dtype=torch.bfloat16, device=dev)
             kw = {"resid": r} if epi == "resid" else {}
-            ms = timeit(lambda: ops.gemm(x, w, b, epilogue=epi, out=o, **kw), a.iters)
-            print(f"gemm M={a.n} N={N} K={K} {epi:6s}: {ms * 1e3:8.1f} us  {2.0 * a.n * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+            sts = a.structures.split(",")
+            best = {st: 1e9 for st in sts}
+            for _ in range(a.rounds):           # interleaved rounds in one process (clock drift hits all structures alike)
+                for st in sts:
+                    best[st] = min(best[st], timeit(lambda: ops.gemm(x, w, b, epilogue=epi, out=o, structure=st, **kw), a.iters))
+            for st in sts:
+                ms = best[st]
+                print(f"gemm M={a.n} N={N} K={K} {epi:6s} {st:6s}: {ms * 1e3:8.1f} us  {2.0 * a.n * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
 def bench_t5(iters):
