@@ -625,6 +625,167 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
     gemm_epilogue<EPI, MT>(p, acc, m_base + (lane & 15), n_base + (lane >> 4) * 4);
 }
 
+// ------------------------------------------------------------------------------------------
+// 128 x 256 tile in the same ping-pong structure, TWO phases per k-tile.  With 64 x 64 per wave a quarter-tile cluster
+// is only 8 MFMAs (128 cycles): shorter than the partner's load segment (fragment reads -> lgkmcnt(0) -> barrier is
+// ~200 cycles of latency), so the 4-phase schedule above ran latency-bound at this tile (measured: 62 % of the
+// matrix rate where the 256-row tile reaches 98 %).  Here a cluster is HALF the sub-tile (all 4 row tiles x 2 column
+// tiles x 2 sub-steps = 16 MFMAs = 256 cycles), and A and B each get a ring of THREE k-tiles (48 + 96 = 144 KiB), so
+// every LDS-DMA request is issued two k-tiles ahead of its first read:
+//     phase 0: read A (8 fragments) + B cols 0,1 (4); request A(t+2);              cluster (rows, cols 0,1)
+//     phase 1: read B cols 2,3 (4); request B(t+2); vmcnt(6) = all but tile t+2;   cluster (rows, cols 2,3)
+// Ring slot (t+2) % 3 was last read in tile t-1 (A: its phase 0, B: its phase 1), retired before that interval's barrier.
+constexpr int PP2_A = 128 * 128, PP2_B = 256 * 128;      // bytes per k-tile
+constexpr int PP2_LDS = 3 * (PP2_A + PP2_B);             // 144 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(PP_THREADS) void gemm_pp2_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  constexpr int GROUP_M = 8;
+  const int width = GROUP_M * p.tiles_n;
+  const int group = wg / width, first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = wg - group * width;
+  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+  const int m0 = tm * 128, n0 = tn * 256;
+
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave + 8 * i) * 8 + (lane >> 3);
+    a_src[i] = p.a + (long)min(m0 + r, p.M - 1) * p.lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave + 8 * i) * 8 + (lane >> 3);
+    w_src[i] = p.w + (long)min(n0 + r, p.N - 1) * p.ldw + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+  }
+  auto dma_a = [&](int slot, int kt) {
+    char* base = smem + slot * PP2_A + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_src[i] + kt * BK, base + i * 8192);
+  };
+  auto dma_b = [&](int slot, int kt) {
+    char* base = smem + 3 * PP2_A + slot * PP2_B + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(w_src[i] + kt * BK, base + i * 8192);
+  };
+
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int swz = (i16 >> 1) & 7;
+  const int x_row_off = (grp * 64 + i16) * 128;
+  const int w_row_off = 3 * PP2_A + (wc * 64 + i16) * 128;
+  const int coff[2] = {((0 + kq) ^ swz) << 4, ((4 + kq) ^ swz) << 4};
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bfr[4][2];
+
+  const int nk = p.K / BK;
+  dma_a(0, 0); dma_b(0, 0);
+  if (nk > 1) { dma_a(1, 1); dma_b(1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+
+  auto end_load_segment = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto cluster = [&](int c0) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][c0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c0 + nt][ks], af[mt][ks], acc[mt][c0 + nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int slot = 0;                       // kt % 3
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* abuf = smem + slot * PP2_A;
+    const char* bbuf = smem + slot * PP2_B;
+    const int nslot = slot == 0 ? 2 : slot - 1;    // (kt + 2) % 3
+    const bool more2 = kt + 2 < nk;
+    // phase 0
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *reinterpret_cast<const bf16x8*>(abuf + x_row_off + mt * 2048 + coff[ks]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bfr[nt][ks] = *reinterpret_cast<const bf16x8*>(bbuf + w_row_off + nt * 2048 + coff[ks]);
+    if (more2) dma_a(nslot, kt + 2);
+    end_load_segment();
+    cluster(0);
+    // phase 1
+#pragma unroll
+    for (int nt = 2; nt < 4; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bfr[nt][ks] = *reinterpret_cast<const bf16x8*>(bbuf + w_row_off + nt * 2048 + coff[ks]);
+    if (more2) {
+      dma_b(nslot, kt + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // everything but tile kt + 2 has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    end_load_segment();
+    cluster(2);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  const int m_base = m0 + grp * 64, n_base = n0 + wc * 64;
+  if ((p.N & 7) == 0 && (p.ldo & 7) == 0)
+    gemm_epilogue_lds<EPI, 4>(p, acc, m_base, n_base, smem + wave * 8192, lane);
+  else
+    gemm_epilogue<EPI, 4>(p, acc, m_base + (lane & 15), n_base + (lane >> 4) * 4);
+}
+
+template <int EPI>
+int launch_pp2(GemmP& p, hipStream_t s) {
+  static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent)
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp2_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, PP2_LDS);
+    attr = true;
+  }
+  p.tiles_m = (p.M + 127) / 128;
+  p.tiles_n = (p.N + 255) / 256;
+  hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(PP_THREADS), PP2_LDS, s, p);
+  return 0;
+}
+
+int launch_pp2_epi(GemmP& p, int epilogue, hipStream_t s) {
+  switch (epilogue) {
+    case SF_EPI_BIAS: return launch_pp2<SF_EPI_BIAS>(p, s);
+    case SF_EPI_BIAS_GELU: return launch_pp2<SF_EPI_BIAS_GELU>(p, s);
+    case SF_EPI_BIAS_RESID: return launch_pp2<SF_EPI_BIAS_RESID>(p, s);
+    case SF_EPI_BIAS_GATE_RESID: return launch_pp2<SF_EPI_BIAS_GATE_RESID>(p, s);
+    default: return -1;
+  }
+}
+
 template <int EPI, int MT>
 int launch_pp(GemmP& p, hipStream_t s) {
   using Cfg = PPCfg<MT>;
@@ -703,14 +864,14 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
         const long tn = (a->N + 255) / 256;
         const long t256 = (long)((a->M + 255) / 256) * tn, t128 = (long)((a->M + 127) / 128) * tn;
         const double e256 = (double)a->M * a->N / (((t256 + 255) / 256) * 256.0 * 256 * 256);
-        const double e128 = (double)a->M * a->N / (((t128 + 255) / 256) * 256.0 * 128 * 256) * 0.93;   // smaller register tile
+        const double e128 = (double)a->M * a->N / (((t128 + 255) / 256) * 256.0 * 128 * 256) * 0.88;   // smaller register tile: k-loop 1240-1300 vs 1450-1500 TFLOP/s
         st = e256 >= e128 ? SF_GEMM_PP256 : SF_GEMM_PP128;
       }
     }
     if ((st == SF_GEMM_PP256 || st == SF_GEMM_PP128) && !pp_ok) st = SF_GEMM_T128;
     if (st == SF_GEMM_T256 && (a->batch > 1 || a->epilogue == SF_EPI_F32)) st = SF_GEMM_T128;
     if (st == SF_GEMM_PP256 || st == SF_GEMM_PP128) {
-      const int rc = st == SF_GEMM_PP256 ? launch_pp_epi<8>(p, a->epilogue, s) : launch_pp_epi<4>(p, a->epilogue, s);
+      const int rc = st == SF_GEMM_PP256 ? launch_pp_epi<8>(p, a->epilogue, s) : launch_pp2_epi(p, a->epilogue, s);
       SF_CHECK(rc == 0, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
       SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
       return 0;
