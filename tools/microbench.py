@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--lk", default="4680,18720,32760")
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--vae-frames", type=int, default=21)
+    ap.add_argument("--batch", type=int, default=1, help="samples per attention launch")
     ap.add_argument("--structures", default="auto", help="GEMM tilings to time, e.g. auto,t128,t256,pp256,pp128")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved timing rounds per (shape, structure); the best is printed")
     a = ap.parse_args()
@@ -39,13 +40,13 @@ def main():
     g = torch.Generator().manual_seed(0)
     C = a.heads * 128
     if "attn" in a.what:
-        q = torch.randn(1, a.n, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+        q = torch.randn(a.batch, a.n, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
         for lk in [int(x) for x in a.lk.split(",")]:
-            k = torch.randn(1, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
-            v = torch.randn(1, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+            k = torch.randn(a.batch, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+            v = torch.randn(a.batch, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
             ms = timeit(lambda: ops.attention(q, k, v), a.iters)
-            fl = 4.0 * C * a.n * lk
-            print(f"attention N={a.n} Lk={lk} H={a.heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+            fl = 4.0 * C * a.n * lk * a.batch
+            print(f"attention B={a.batch} N={a.n} Lk={lk} H={a.heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
     if "t5" in a.what:
         bench_t5(max(2, a.iters // 2))
     if "vae" in a.what:
