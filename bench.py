@@ -98,6 +98,30 @@ def time_kernel(fn, iters):
     return e0.elapsed_time(e1) / iters  # ms
 
 
+def time_graph(fn, iters):
+    """Mean device time of `fn`'s kernels with the launches replayed from a HIP graph: for kernels of a few
+    microseconds the Python call (allocation + dispatcher + ctypes) takes longer than the kernel, and timing eager
+    launches measures the host."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(iters):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
 def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
     """Average launch duration of the self-attention kernel over the Lk values one rollout visits
     (each chunk index launches it equally often), and of the biggest GEMM, from events on the
@@ -153,7 +177,8 @@ def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
 
 def hbm_bound_leg(shape, dev, nfpb, fs):
     """The HBM-bound kernels of a forward (reported as GB/s): algorithmic bytes per launch / mean launch
-    duration (events on the launch stream), against the 8 TB/s HBM3E peak.  Shapes of one S1 forward."""
+    duration (50 launches replayed from a HIP graph, events around the replay: back-to-back device time including the
+    ~1.5 us kernel boundary), against the 8 TB/s HBM3E peak.  Shapes of one S1 forward."""
     HBM_PEAK = 8000.0
     n, C, H = nfpb * fs, shape.dim, shape.num_heads
     g = torch.Generator(device="cpu").manual_seed(2)
@@ -165,7 +190,7 @@ def hbm_bound_leg(shape, dev, nfpb, fs):
         gbs = nbytes / (ms * 1e-3) / 1e9
         res[name] = {"GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK, "us": 1e3 * ms, "algorithmic_bytes": nbytes, "bytes": what}
 
-    ms = time_kernel(lambda: ops.layernorm_modulate(x, mod[0], mod[1], e0[:, :C], e0[:, C:2 * C], fs), 50)
+    ms = time_graph(lambda: ops.layernorm_modulate(x, mod[0], mod[1], e0[:, :C], e0[:, C:2 * C], fs), 50)
     add("layernorm_kernel (LN + AdaLN modulate)", ms, 2 * n * C * 2, "x read + y written")
     qkv = rb(n, 3 * C)
     kc = torch.zeros(1, n, H, 128, dtype=torch.bfloat16, device=dev)
@@ -173,10 +198,10 @@ def hbm_bound_leg(shape, dev, nfpb, fs):
     nq, nk = rb(C), rb(C)
     from self_forcing_amd.model import rope_tables
     cos, sin = (t.to(dev) for t in rope_tables(128))
-    ms = time_kernel(lambda: ops.qkv_norm_rope_cache(qkv, nq, nk, kc, vc, cos, sin, (nfpb, LAT_H // 2, LAT_W // 2), 0, 0), 50)
+    ms = time_graph(lambda: ops.qkv_norm_rope_cache(qkv, nq, nk, kc, vc, cos, sin, (nfpb, LAT_H // 2, LAT_W // 2), 0, 0), 50)
     add("qkv_norm_rope_cache_kernel (QK-RMSNorm + RoPE + cache append)", ms, 6 * n * C * 2, "qkv read; q, K rows, V rows written")
     xs, w6, b6 = rb(nfpb, C), rb(6 * C, C), rb(6 * C)
-    ms = time_kernel(lambda: ops.small_linear(xs, w6, b6, act_in="silu"), 50)
+    ms = time_graph(lambda: ops.small_linear(xs, w6, b6, act_in="silu"), 50)
     add("small_linear_kernel (time projection, M = 3)", ms, 6 * C * C * 2, "weights read once")
     return res
 
