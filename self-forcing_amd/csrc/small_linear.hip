@@ -10,14 +10,17 @@
 
 namespace {
 
-constexpr int SL_MB = 8;        // activation rows per pass
+constexpr int SL_MB_MAX = 8;    // activation rows per pass (the kernel is instantiated for 1, 2, 3, 4 and 8 rows: with the
+                                // rollout's M = 3 an 8-row pass spent 2.7x the FMAs and wave reductions the rows need and
+                                // ran VALU-bound at 1.3 TB/s of weights)
 constexpr int SL_THREADS = 256;
-constexpr int SL_NPW = 2;       // output columns per wave per iteration (independent loads in flight)
+constexpr int SL_NPW = 4;       // output columns per wave per iteration (independent 16-byte loads in flight)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   return act == 1 ? silu_f(v) : (act == 2 ? gelu_tanh_f(v) : v);
 }
 
+template <int SL_MB>
 __global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                                   const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
                                                                   int m0, int mcount, int N, int K, int act_in, int act_out) {
@@ -78,15 +81,21 @@ extern "C" int sf_small_linear(const void* x, const void* w, const void* bias, v
                                int act_in, int act_out, void* stream) {
   SF_CHECK(x && w && out, "sf_small_linear: null tensor");
   SF_CHECK(M > 0 && M <= 32 && N > 0 && K > 0 && K % 8 == 0, "sf_small_linear: unsupported shape M=%d N=%d K=%d (M<=32, K%%8==0)", M, N, K);
-  SF_CHECK((size_t)SL_MB * K * 2 <= 160 * 1024, "sf_small_linear: K=%d too large for the LDS activation stage", K);
+  SF_CHECK((size_t)SL_MB_MAX * K * 2 <= 160 * 1024, "sf_small_linear: K=%d too large for the LDS activation stage", K);
   SF_CHECK(act_in >= 0 && act_in <= 2 && act_out >= 0 && act_out <= 2, "sf_small_linear: bad activation code");
   const int waves_needed = (N + SL_NPW - 1) / SL_NPW;
   const int blocks = min(1024, (waves_needed + 3) / 4);
-  const size_t lds = (size_t)SL_MB * K * 2;
-  for (int m0 = 0; m0 < M; m0 += SL_MB) {
-    const int mc = min(SL_MB, M - m0);
-    hipLaunchKernelGGL(small_linear_kernel, dim3(blocks), dim3(SL_THREADS), lds, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)w, (const bf16_t*)bias, (bf16_t*)out, m0, mc, N, K, act_in, act_out);
+  for (int m0 = 0; m0 < M; m0 += SL_MB_MAX) {
+    const int mc = min(SL_MB_MAX, M - m0);
+#define SF_SL_LAUNCH(R)                                                                                                  \
+  hipLaunchKernelGGL(small_linear_kernel<R>, dim3(blocks), dim3(SL_THREADS), (size_t)R * K * 2, (hipStream_t)stream,      \
+                     (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)bias, (bf16_t*)out, m0, mc, N, K, act_in, act_out)
+    if (mc == 1) SF_SL_LAUNCH(1);
+    else if (mc == 2) SF_SL_LAUNCH(2);
+    else if (mc == 3) SF_SL_LAUNCH(3);
+    else if (mc == 4) SF_SL_LAUNCH(4);
+    else SF_SL_LAUNCH(8);
+#undef SF_SL_LAUNCH
   }
   SF_HIP_LAUNCH_CHECK("sf_small_linear");
   return 0;
