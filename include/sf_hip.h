@@ -66,10 +66,8 @@ typedef struct sf_gemm_args {
 } sf_gemm_args;
 
 enum sf_gemm_structure { SF_GEMM_AUTO = 0, SF_GEMM_T128 = 1 /* 128 x 128 tile, 4 waves, 2 workgroups / CU */,
-                         SF_GEMM_T256 = 2 /* 256 x 256 tile, 8 waves in lockstep, 1 workgroup / CU */,
-                         SF_GEMM_PP256 = 3 /* 256 x 256 tile, 8 waves, the two waves of a SIMD half a phase apart */,
-                         SF_GEMM_PP128 = 4 /* 128 x 256 tile, same structure */,
-                         SF_GEMM_PPP256 = 5 /* SF_GEMM_PP256 as a persistent kernel: the pipeline runs across tile boundaries */ };
+                         SF_GEMM_PP256 = 2 /* 256 x 256 tile, 8 waves, the two waves of a SIMD half a phase apart */,
+                         SF_GEMM_PP128 = 3 /* 128 x 256 tile, same structure, two phases per k-tile, 3-deep rings */ };
 
 int sf_gemm_bf16(const sf_gemm_args* args, void* stream);
 

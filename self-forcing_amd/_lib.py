@@ -23,7 +23,7 @@ VAE_MAX_STAGES = 4
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 # enum sf_attn_structure / sf_gemm_structure
 ATTN_STRUCTURES = {"auto": 0, "r64": 1, "w8": 2, "w4": 3}
-GEMM_STRUCTURES = {"auto": 0, "t128": 1, "t256": 2, "pp256": 3, "pp128": 4, "ppp256": 5}
+GEMM_STRUCTURES = {"auto": 0, "t128": 1, "pp256": 2, "pp128": 3}
 
 
 class GemmArgs(C.Structure):

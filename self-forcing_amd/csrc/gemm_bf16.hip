@@ -317,135 +317,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
 
 
 // ------------------------------------------------------------------------------------------
-// Large-tile structure for wide GEMMs (ffn.0): 256 x 256 output tile per 512-thread workgroup, 8 waves as
-// 2 x 4, 128 x 64 per wave (8 x 4 MFMA tiles), ONE workgroup per CU (two waves per SIMD), two 64 KiB
-// stages.  Per kflop it moves 31 B through LDS instead of 47 (fragment reads 23 + tile writes 8), the
-// measured limiter of the 128 x 128 kernel (tools/probes/gemm_probe.hip: 1481 vs 1050 TFLOP/s for the bare
-// loops).  Only worth it when the tile count fills the 256 CUs in nearly whole rounds.
-constexpr int BBM = 256, BBN = 256;
-constexpr int BIG_THREADS = 512;
-constexpr int BIG_TILE_BYTES = BBM * BK * 2;      // 32 KiB per operand tile
-constexpr int BIG_STAGE = 2 * BIG_TILE_BYTES;
-constexpr int BIG_LDS = 2 * BIG_STAGE;            // 128 KiB
-
-template <int EPI>
-__global__ __launch_bounds__(BIG_THREADS) void gemm_big_kernel(GemmP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GROUP_M = 4;
-  const int width = GROUP_M * p.tiles_n;
-  const int group = wg / width, first_m = group * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int in_group = wg - group * width;
-  const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-  const int m0 = tm * BBM, n0 = tn * BBN;
-
-  // staging: wave w issues pieces 4w .. 4w+3 (8 rows x 128 B each) of the A tile and of the W tile
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    a_src[i] = p.a + (long)min(m0 + r, p.M - 1) * p.lda + c * 8;
-    w_src[i] = p.w + (long)min(n0 + r, p.N - 1) * p.ldw + c * 8;
-  }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * BIG_STAGE + wave * 4096;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(a_src[i] + k0, base + i * 1024);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(w_src[i] + k0, base + BIG_TILE_BYTES + i * 1024);
-  };
-
-  const int wr = wave >> 2, wc = wave & 3;
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int swz = (i16 >> 1) & 7;
-  const int x_row_off = (wr * 128 + i16) * 128;
-  const int w_row_off = BIG_TILE_BYTES + (wc * 64 + i16) * 128;
-  const int coff[2] = {((0 + kq) ^ swz) << 4, ((4 + kq) ^ swz) << 4};
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  bf16x8 xf0[8], wf0[4], xf1[8], wf1[4];
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const char* buf = smem + cur * BIG_STAGE;
-    // eight pinned slices of {4 MFMAs of the first sub-step, fragment reads of the second, ONE LDS-DMA request of
-    // the next tile} (see gemm_bf16_kernel), then the second sub-step's 32 MFMAs
-    const int kn = min(kt + 1, nk - 1) * BK;
-    char* sbase = smem + (cur ^ 1) * BIG_STAGE + wave * 4096;
-#ifdef SF_ABL_BIG_NOREAD0   // timing only: the up-front fragment reads of the first sub-step
-    if (kt == 0) {
-#endif
-#pragma unroll
-    for (int t = 0; t < 8; ++t) xf0[t] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + t * 2048 + coff[0]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wf0[t] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + t * 2048 + coff[0]);
-#ifdef SF_ABL_BIG_NOREAD0
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], xf0[i], acc[i][nt], 0, 0, 0);
-      xf1[i] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + i * 2048 + coff[1]);
-      if (i < 4) {
-        wf1[i] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + i * 2048 + coff[1]);
-        glds16(a_src[i] + kn, sbase + i * 1024);
-      } else {
-        glds16(w_src[i - 4] + kn, sbase + BIG_TILE_BYTES + (i - 4) * 1024);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], xf1[mt], acc[mt][nt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#ifdef SF_ABL_BIG_NOBAR     // timing only: no workgroup barrier (each wave still waits for its own LDS-DMA)
-    __builtin_amdgcn_s_waitcnt(0);
-#else
-    __syncthreads();
-#endif
-  }
-  const int mrow = m0 + wr * 128 + (lane & 15);
-  const int ncol = n0 + wc * 64 + (lane >> 4) * 4;
-#ifdef SF_ABL_NOEPI   // timing-only: one store per thread keeps the accumulators alive
-  float sacc = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-  if (mrow < p.M && ncol < p.N) p.out[(long)mrow * p.ldo + ncol] = (bf16_t)sacc;
-#else
-  if ((p.N & 7) == 0 && (p.ldo & 7) == 0)   // (the trailing __syncthreads of the k-loop has released the stages)
-    gemm_epilogue_lds<EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, smem + wave * 16384, lane);
-  else
-    gemm_epilogue<EPI, 8>(p, acc, mrow, ncol);
-#endif
-}
-
-
-// ------------------------------------------------------------------------------------------
 // Ping-pong structure ("pp"): (32 MT) x 256 output tile per 512-thread workgroup, 8 waves as 2 (M) x 4 (N), one
 // workgroup per CU.  The two waves that share a SIMD (wave w and w + 4: the two M halves) run ONE BARRIER INTERVAL
 // APART: while one issues its MFMA cluster (a quarter of its sub-tile x one 64-deep k-tile, from registers) the other
@@ -623,214 +494,6 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
     gemm_epilogue_lds<EPI, MT>(p, acc, m_base, n_base, smem + wave * (MT * 2048), lane);
   else
     gemm_epilogue<EPI, MT>(p, acc, m_base + (lane & 15), n_base + (lane >> 4) * 4);
-}
-
-// ------------------------------------------------------------------------------------------
-// PERSISTENT form of the 256 x 256 ping-pong kernel: at most one workgroup per CU walks its tiles (wg, wg + G, ...),
-// and the software pipeline simply CONTINUES across the tile boundary: the LDS-DMA slots that would request k-tiles
-// nk, nk + 1 of the current tile request k-tiles 0, 1 of the NEXT one (nk even: same buffer parity), so a tile after
-// the first has no prologue at all -- its first fragments are in LDS when the previous tile's last cluster retires.
-// The epilogue runs between the tiles WITHOUT a workgroup barrier: the two wave groups are one interval apart, so one
-// group's epilogue (bias / GELU / gate / residual, transpose through LDS, stores) overlaps the other group's last /
-// first MFMA clusters.  It cannot use the stages (they hold the next tile's data): each wave transposes its sub-tile
-// in two halves through 8 KiB of scratch -- waves 0-3 in buffer 1's A region (dead between its last read, two
-// intervals before the epilogue, and the next tile's A(1) requests, issued by each wave after its own epilogue and by
-// the other group after theirs, when waves 0-3 are long done), waves 4-7 in the 32 KiB above the stages (160 KiB).
-constexpr int PPP_LDS = 160 * 1024;
-
-template <int EPI>
-__global__ __launch_bounds__(PP_THREADS) void gemm_ppp_kernel(GemmP p) {
-  using Cfg = PPCfg<8>;
-  constexpr int MT = 8, HQ = 4, PA = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wc = wave & 3;
-
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ntiles = p.tiles_m * p.tiles_n;
-
-  const bf16_t* a_src[2][PA];
-  const bf16_t* w_src[2][2];
-  const bf16_t* a_nxt[2][PA];
-  const bf16_t* w_nxt[2][2];
-  auto tile_origin = [&](int tile, int& m0, int& n0) {
-    constexpr int GROUP_M = 4;
-    const int width = GROUP_M * p.tiles_n;
-    const int group = tile / width, first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int in_group = tile - group * width;
-    m0 = (first_m + in_group % gsz) * 256;
-    n0 = (in_group / gsz) * 256;
-  };
-  auto sources = [&](int m0, int n0, const bf16_t* (&as)[2][PA], const bf16_t* (&wsrc)[2][2]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int r = h * 128 + (wave + 8 * i) * 8 + (lane >> 3);
-        as[h][i] = p.a + (long)min(m0 + r, p.M - 1) * p.lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-        wsrc[h][i] = p.w + (long)min(n0 + r, p.N - 1) * p.ldw + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-      }
-    }
-  };
-  auto dma_a = [&](const bf16_t* (&as)[2][PA], int h, int buf, int k0) {
-    char* base = smem + buf * Cfg::STAGE + h * (Cfg::A_BYTES / 2) + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(as[h][i] + k0, base + i * 8192);
-  };
-  auto dma_b = [&](const bf16_t* (&wsrc)[2][2], int h, int buf, int k0) {
-    char* base = smem + buf * Cfg::STAGE + Cfg::A_BYTES + h * (Cfg::B_BYTES / 2) + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(wsrc[h][i] + k0, base + i * 8192);
-  };
-
-  const int i16 = lane & 15, kq = lane >> 4;
-  const int swz = (i16 >> 1) & 7;
-  const int x_row_off = (grp * 128 + i16) * 128;
-  const int w_row_off = Cfg::A_BYTES + (wc * 64 + i16) * 128;
-  const int coff[2] = {((0 + kq) ^ swz) << 4, ((4 + kq) ^ swz) << 4};
-  // epilogue scratch: 8 KiB per wave (see above)
-  char* const scratch = smem + (grp == 0 ? Cfg::STAGE + wave * 8192 : 2 * Cfg::STAGE + (wave - 4) * 8192);
-
-  f32x4 acc[MT][4];
-  bf16x8 af[HQ][2], bfr[4][2];
-  const int nk = p.K / BK;
-
-  auto end_load_segment = [&]() {
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto cluster = [&](int q, int c0) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < HQ; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          acc[q * HQ + mt][c0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c0 + nt][ks], af[mt][ks], acc[q * HQ + mt][c0 + nt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto read_a = [&](const char* buf, int q) {
-#pragma unroll
-    for (int mt = 0; mt < HQ; ++mt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        af[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + (q * HQ + mt) * 2048 + coff[ks]);
-  };
-  auto read_b = [&](const char* buf, int c0) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bfr[c0 + nt][ks] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + (c0 + nt) * 2048 + coff[ks]);
-  };
-
-  int tile = wg;
-  int m0, n0;
-  tile_origin(tile, m0, n0);
-  sources(m0, n0, a_src, w_src);
-  // prologue of the FIRST tile only: A(0), B(0), then B(1) which may still be in flight when k-tile 0 starts
-  dma_a(a_src, 0, 0, 0); dma_a(a_src, 1, 0, 0); dma_b(w_src, 0, 0, 0); dma_b(w_src, 1, 0, 0);
-  dma_b(w_src, 0, 1, BK); dma_b(w_src, 1, 1, BK);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();
-
-  while (true) {
-    const int next = tile + nwg;
-    const bool has_next = next < ntiles;
-    int m1 = 0, n1 = 0;
-    if (has_next) {
-      tile_origin(next, m1, n1);
-      sources(m1, n1, a_nxt, w_nxt);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* buf = smem + (kt & 1) * Cfg::STAGE;
-      const int b1 = (kt + 1) & 1;
-      const bool cur1 = kt + 1 < nk, cur2 = kt + 2 < nk;      // the k-tile one / two ahead belongs to this tile
-      const bool more1 = cur1 || has_next, more2 = cur2 || has_next;
-      // phase 0
-      read_a(buf, 0);
-      read_b(buf, 0);
-      if (cur1) dma_a(a_src, 0, b1, (kt + 1) * BK); else if (has_next) dma_a(a_nxt, 0, b1, 0);
-      end_load_segment();
-      cluster(0, 0);
-      // phase 1
-      read_b(buf, 2);
-      if (cur1) dma_a(a_src, 1, b1, (kt + 1) * BK); else if (has_next) dma_a(a_nxt, 1, b1, 0);
-      end_load_segment();
-      cluster(0, 2);
-      // phase 2
-      read_a(buf, 1);
-      if (cur2) dma_b(w_src, 0, kt & 1, (kt + 2) * BK); else if (has_next) dma_b(w_nxt, 0, kt & 1, (kt + 2 - nk) * BK);
-      end_load_segment();
-      cluster(1, 2);
-      // phase 3
-      if (cur2) dma_b(w_src, 1, kt & 1, (kt + 2) * BK); else if (has_next) dma_b(w_nxt, 1, kt & 1, (kt + 2 - nk) * BK);
-      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      (void)more1;
-      end_load_segment();
-      cluster(1, 0);
-    }
-
-    // ---- epilogue of this tile, no workgroup barrier (the partner group is in its last / the next tile's first clusters)
-    const int m_base = m0 + grp * 128, n_base = n0 + wc * 64;
-    if ((p.N & 7) == 0 && (p.ldo & 7) == 0) {
-      gemm_epilogue_lds<EPI, 4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[0]), m_base, n_base, scratch, lane);
-      __builtin_amdgcn_s_waitcnt(0xc07f);          // the scratch rows of the first half are read: reuse them
-      gemm_epilogue_lds<EPI, 4>(p, reinterpret_cast<f32x4(&)[4][4]>(acc[4]), m_base + 64, n_base, scratch, lane);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-    } else {
-      gemm_epilogue<EPI, MT>(p, acc, m_base + (lane & 15), n_base + (lane >> 4) * 4);
-    }
-    if (!has_next) break;
-    tile = next; m0 = m1; n0 = n1;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { a_src[h][i] = a_nxt[h][i]; w_src[h][i] = w_nxt[h][i]; }
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-}
-
-template <int EPI>
-int launch_ppp(GemmP& p, hipStream_t s) {
-  static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent)
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ppp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, PPP_LDS);
-    attr = true;
-  }
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  const int tiles = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((gemm_ppp_kernel<EPI>), dim3(min(tiles, 256)), dim3(PP_THREADS), PPP_LDS, s, p);
-  return 0;
-}
-
-int launch_ppp_epi(GemmP& p, int epilogue, hipStream_t s) {
-  switch (epilogue) {
-    case SF_EPI_BIAS: return launch_ppp<SF_EPI_BIAS>(p, s);
-    case SF_EPI_BIAS_GELU: return launch_ppp<SF_EPI_BIAS_GELU>(p, s);
-    case SF_EPI_BIAS_RESID: return launch_ppp<SF_EPI_BIAS_RESID>(p, s);
-    case SF_EPI_BIAS_GATE_RESID: return launch_ppp<SF_EPI_BIAS_GATE_RESID>(p, s);
-    default: return -1;
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1019,20 +682,6 @@ int launch_pp_epi(GemmP& p, int epilogue, hipStream_t s) {
   }
 }
 
-template <int EPI>
-int launch_big(GemmP& p, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
-    attr = true;
-  }
-  p.tiles_m = (p.M + BBM - 1) / BBM;
-  p.tiles_n = (p.N + BBN - 1) / BBN;
-  hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(p.tiles_m * p.tiles_n), dim3(BIG_THREADS), BIG_LDS, s, p);
-  return 0;
-}
-
-
 }  // namespace
 
 extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
@@ -1060,7 +709,7 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
   p.tiles_n = (a->N + BN - 1) / BN;
   hipStream_t s = (hipStream_t)stream;
   p.tiles_m = (a->M + BM - 1) / BM;
-  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_PPP256, "sf_gemm_bf16: unknown structure %d", a->structure);
+  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_PP128, "sf_gemm_bf16: unknown structure %d", a->structure);
   {
     int st = a->structure;
     const bool pp_ok = a->batch <= 1 && a->epilogue != SF_EPI_F32 && a->K >= 2 * BK;
@@ -1076,30 +725,10 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
         st = e256 >= e128 ? SF_GEMM_PP256 : SF_GEMM_PP128;
       }
     }
-    if ((st == SF_GEMM_PP256 || st == SF_GEMM_PP128 || st == SF_GEMM_PPP256) && !pp_ok) st = SF_GEMM_T128;
-    // the persistent form needs an even number of k-tiles (>= 4): buffer parity carries over the tile boundary
-    if (st == SF_GEMM_PPP256 && ((a->K / BK) % 2 != 0 || a->K / BK < 4)) st = SF_GEMM_PP256;
-    if (st == SF_GEMM_PPP256) {
-      const int rc = launch_ppp_epi(p, a->epilogue, s);
-      SF_CHECK(rc == 0, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
-      SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
-      return 0;
-    }
-    if (st == SF_GEMM_T256 && (a->batch > 1 || a->epilogue == SF_EPI_F32)) st = SF_GEMM_T128;
+    if ((st == SF_GEMM_PP256 || st == SF_GEMM_PP128) && !pp_ok) st = SF_GEMM_T128;
     if (st == SF_GEMM_PP256 || st == SF_GEMM_PP128) {
       const int rc = st == SF_GEMM_PP256 ? launch_pp_epi<8>(p, a->epilogue, s) : launch_pp2_epi(p, a->epilogue, s);
       SF_CHECK(rc == 0, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
-      SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
-      return 0;
-    }
-    if (st == SF_GEMM_T256) {
-      switch (a->epilogue) {
-        case SF_EPI_BIAS: launch_big<SF_EPI_BIAS>(p, s); break;
-        case SF_EPI_BIAS_GELU: launch_big<SF_EPI_BIAS_GELU>(p, s); break;
-        case SF_EPI_BIAS_RESID: launch_big<SF_EPI_BIAS_RESID>(p, s); break;
-        case SF_EPI_BIAS_GATE_RESID: launch_big<SF_EPI_BIAS_GATE_RESID>(p, s); break;
-        default: SF_CHECK(false, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
-      }
       SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
       return 0;
     }

@@ -112,8 +112,8 @@ def test_gemm_rejects_bad_shapes():
 
 @pytest.mark.parametrize("epi", ["bias", "gelu", "gate_resid"])
 def test_gemm_large_tile_structure(epi):
-    """Wide outputs whose 256 x 256 tiles fill the chip dispatch the 8-wave large-tile kernel (ffn.0's shape);
-    ragged M (4680 = 18 x 256 + 72) exercises its row clamping."""
+    """Wide outputs whose 256 x 256 tiles fill the chip dispatch the 8-wave ping-pong kernel (ffn.0's shape, 3 k-tiles
+    here: its prologue / tail paths); ragged M (4680 = 18 x 256 + 72) exercises its row clamping."""
     M, N, K = 4680, 8960, 192
     g = torch.Generator().manual_seed(77)
     a, w, bias = bf((M, K), g), bf((N, K), g, 1.0 / K ** 0.5), bf((N,), g, 0.5)
@@ -132,7 +132,7 @@ def test_gemm_large_tile_structure(epi):
     assert rel(out, ref) < 4e-3
 
 
-@pytest.mark.parametrize("structure", ["t128", "t256", "pp256", "pp128", "ppp256"])
+@pytest.mark.parametrize("structure", ["t128", "pp256", "pp128"])
 @pytest.mark.parametrize("M,N,K,epi", [(4680, 1536, 1536, "gate_resid"), (4680, 4608, 1536, "bias"), (1560, 8960, 1536, "gelu"),
                                        (4680, 1536, 8960, "gate_resid"), (10800, 5120, 5120, "resid"), (1100, 1288, 128, "gelu"),
                                        (257, 264, 192, "resid"), (3000, 1024, 64, "bias"), (9360, 8960, 512, "gelu"), (9360, 4608, 1536, "bias")])
@@ -173,7 +173,7 @@ def test_gemm_pingpong_is_race_free_under_repetition():
     side = torch.cuda.Stream()
     junk = torch.empty(64 << 20, dtype=torch.bfloat16, device=DEV)
     for (M, N, K, st) in [(4680, 1536, 8960, "pp128"), (4680, 8960, 1536, "pp256"), (4680, 4608, 1536, "pp128"), (2048, 2048, 2048, "pp256"),
-                          (9360, 8960, 1536, "ppp256"), (9360, 4608, 1536, "ppp256"), (4680, 8960, 256, "ppp256"), (9360, 1536, 8960, "ppp256")]:
+                          (9360, 8960, 1536, "pp256"), (9360, 1536, 8960, "pp256")]:
         a, w = bf((M, K), g).to(DEV), bf((N, K), g, 1.0 / K ** 0.5).to(DEV)
         first = ops.gemm(a, w, None, structure=st)
         assert rel(first, a.float().cpu() @ w.float().cpu().t()) < 4e-3
