@@ -414,12 +414,19 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[HQ][2], bfr[4][2];
 
+#ifdef SF_STAMP   // diagnostic build (tools/probes/gemm_stamp.py): where a tile's time goes; stamps go to a buffer of their own
+  unsigned long long* stamp = (EPI == SF_EPI_BIAS && p.gate_e0) ? reinterpret_cast<unsigned long long*>(const_cast<bf16_t*>(p.gate_e0)) + ((long)bid * 2 + grp) * 8 : nullptr;
+  if (stamp && (tid & 255) == 0) { stamp[0] = __builtin_amdgcn_s_memtime(); stamp[4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   const int nk = p.K / BK;
   // prologue: A(0), B(0), then B(1) which may still be in flight when tile 0 starts (same count as in the loop)
   dma_a(0, 0); dma_a(1, 0); dma_b(0, 0); dma_b(1, 0);
   if (nk > 1) { dma_b(0, 1); dma_b(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef SF_STAMP
+  if (stamp && (tid & 255) == 0) stamp[1] = __builtin_amdgcn_s_memtime();
+#endif
   if (grp == 1) __builtin_amdgcn_s_barrier();       // the second wave group runs one interval behind the first
 
   auto end_load_segment = [&]() {
@@ -487,6 +494,9 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
     cluster(1, 0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with the extra barrier of the second group: all clusters done
+#ifdef SF_STAMP
+  if (stamp && (tid & 255) == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue (no LDS-DMA is in flight, every fragment read is retired: the stages are free)
   const int m_base = m0 + grp * (BMp / 2), n_base = n0 + wc * 64;
@@ -494,6 +504,10 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
     gemm_epilogue_lds<EPI, MT>(p, acc, m_base, n_base, smem + wave * (MT * 2048), lane);
   else
     gemm_epilogue<EPI, MT>(p, acc, m_base + (lane & 15), n_base + (lane >> 4) * 4);
+#ifdef SF_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamp && (tid & 255) == 0) { stamp[3] = __builtin_amdgcn_s_memtime(); stamp[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
