@@ -807,25 +807,14 @@ __global__ __launch_bounds__(256) void attention_r64_sk_kernel(AttP p, SkP k) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  // The workgroup's unit range [w c, (w + 1) c) is the TAIL of one pair's key range followed by the HEAD of the next
-  // pair's.  The head segment runs FIRST: then every workgroup is at key tile `time` while it is in its head segment
-  // and at key tile `time + (T - c)` while in its tail segment (tail start - head length = T - c for every workgroup),
-  // so the workgroups of a head still walk its K / V tiles in two lockstep fronts and share them in their XCD's L2.
-  // Run in unit order instead, every workgroup sits at its own tile position and each streams its K / V from HBM
-  // alone: 3.9 GB per launch instead of 0.28 GB at Lk = 32760 (measured), and the kernel is slower than unsplit.
   const long U = (long)k.P * k.T;
-  const long u_begin = (long)w * k.c;
-  const long u_end = min(u_begin + k.c, U);
-  const long boundary = min(u_end, (u_begin / k.T + 1) * k.T);          // end of the first pair's units inside the range
+  long u = (long)w * k.c;
+  const long u_end = min(u + k.c, U);
 #pragma unroll 1
-  for (int seg = 0; seg < 2; ++seg) {
-    // seg 0: the head of the second pair [boundary, u_end) if there is one; seg 1: the tail of the first [u_begin, boundary)
-    const long u = seg == 0 ? boundary : u_begin;
-    const long ue = seg == 0 ? u_end : boundary;
-    if (u >= ue) continue;
+  while (u < u_end) {
     const int s = (int)(u / k.T);
     const int t0 = (int)(u - (long)s * k.T);
-    const int t1 = t0 + (int)(ue - u);
+    const int t1 = (int)min((long)k.T, t0 + (u_end - u));
     int bh, qt;
     sk_pair(p, k.P, s, bh, qt);
     const bool whole = t0 == 0 && t1 == k.T;
@@ -907,6 +896,7 @@ __global__ __launch_bounds__(256) void attention_r64_sk_kernel(AttP p, SkP k) {
       }
       __syncthreads();
     }
+    u += t1 - t0;
     __syncthreads();
   }
 }
