@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 6
+#define SF_HIP_ABI_VERSION 5
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -127,25 +127,13 @@ int sf_attention(const void* q, const void* k, const void* v, void* out, int B, 
                  int64_t o_stride, int64_t o_bstride, void* stream);
 
 /* The same with the kernel structure named by the caller instead of picked from the shape (tests and A/B timing;
- * every structure computes every shape it accepts): SF_ATTN_R64 = 64 query rows per wave, one wave per SIMD,
- * hand-scheduled (256 rows per workgroup); SF_ATTN_W8 = 8-wave anti-phase workgroups of 256 rows; SF_ATTN_W4 = 4-wave
- * workgroups of 128 rows; SF_ATTN_R64_SK = the R64 kernel on all 256 CUs with the key range split stream-K fashion and
- * the partial (O, m, l) merged by the last-arriving workgroup (needs the workspace of sf_attention_ws).
- * sf_attention == sf_attention_ex(..., SF_ATTN_AUTO, stream) == sf_attention_ws(..., SF_ATTN_AUTO, NULL, 0, stream). */
-enum sf_attn_structure { SF_ATTN_AUTO = 0, SF_ATTN_R64 = 1, SF_ATTN_W8 = 2, SF_ATTN_W4 = 3, SF_ATTN_R64_SK = 4 };
+ * every structure computes every shape): SF_ATTN_R64 = 64 query rows per wave, one wave per SIMD, hand-scheduled
+ * (256 rows per workgroup); SF_ATTN_W8 = 8-wave anti-phase workgroups of 256 rows; SF_ATTN_W4 = 4-wave workgroups of
+ * 128 rows.  sf_attention == sf_attention_ex(..., SF_ATTN_AUTO, stream). */
+enum sf_attn_structure { SF_ATTN_AUTO = 0, SF_ATTN_R64 = 1, SF_ATTN_W8 = 2, SF_ATTN_W4 = 3 };
 int sf_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
                     int64_t q_stride, int64_t q_bstride, int64_t kv_stride, int64_t kv_bstride,
                     int64_t o_stride, int64_t o_bstride, int structure, void* stream);
-
-/* With a caller-provided workspace (256-byte aligned device memory, contents irrelevant, private to the stream while the
- * call is in flight): lets SF_ATTN_AUTO choose SF_ATTN_R64_SK when the (batch x head x 256-row tile) grid has between
- * 129 and 255 workgroups -- the rollout's self-attention: 12 heads x 19 tiles = 228 on 256 CUs -- and the cache is at
- * least 8192 keys long.  sf_attention_workspace_bytes returns the size that shape needs (0: the split never applies). */
-size_t sf_attention_workspace_bytes(int B, int H, int Lq);
-int sf_attention_ws(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq, int Lk,
-                    int64_t q_stride, int64_t q_bstride, int64_t kv_stride, int64_t kv_bstride,
-                    int64_t o_stride, int64_t o_bstride, int structure, void* workspace, size_t workspace_bytes,
-                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Patch gather for the (1,2,2) Conv3d patch embedding, causal_model.py:458-459, :775-781:

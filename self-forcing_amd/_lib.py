@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 6
+ABI_VERSION = 5
 
 # epilogue codes (enum sf_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
@@ -22,7 +22,7 @@ CONV_BIAS, CONV_BIAS_RESID, CONV_BIAS_CLAMP_F32 = 0, 1, 2
 VAE_MAX_STAGES = 4
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 # enum sf_attn_structure / sf_gemm_structure
-ATTN_STRUCTURES = {"auto": 0, "r64": 1, "w8": 2, "w4": 3, "r64_sk": 4}
+ATTN_STRUCTURES = {"auto": 0, "r64": 1, "w8": 2, "w4": 3}
 GEMM_STRUCTURES = {"auto": 0, "t128": 1, "pp256": 2, "pp128": 3}
 
 
@@ -137,8 +137,6 @@ SIGNATURES = {
     "sf_kv_evict": (C.c_int, [_vp, _i, _i64, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sf_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "sf_attention_ex": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp]),
-    "sf_attention_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
-    "sf_attention_ws": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i, _vp, _sz, _vp]),
     "sf_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sf_unpatchify_x0": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_add_noise": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i64, _vp]),

@@ -645,22 +645,25 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
 // body through LDS; tools/gen_attention_r64.py documents the register map and the pipeline.
 constexpr int QT64 = 256;                      // 4 waves x 64 rows
 constexpr int ATT64_LDS = 7 * TILE_B;          // K ring of 4 + V ring of 3 = 112 KiB
-// a partial result of one (pair, key segment): 256 rows x 128 fp32 of unnormalised O, then m (log2 units), then l
-constexpr int SK_SLOT_FLOATS = QT64 * HD + 2 * QT64;
-constexpr int SK_MAX_PARTS = 3;
-constexpr int SK_MIN_TILES = 128;             // SF_ATTN_AUTO splits the key range from this many key tiles on (Lk >= 8192)
 
-// Workgroup -> (batch * head, query tile), XCD-aware (placement affects speed only): workgroups bid and bid + 8 share an
-// XCD and its L2.  Every query tile of a (batch, head) pair streams the same K / V slab, so a pair's tiles should sit
-// on ONE XCD: each XCD first takes f = floor(slots / q_tiles) whole pairs; the pairs left over fill the XCDs'
-// remaining slots in the order 0,4,1,5,2,6,3,7 -- the round-robin gives the first (nwg & 7) XCDs one slot more, so
-// this order pairs a larger remainder with a smaller one and a split pair spans two XCDs, not three.  At the
-// rollout's shape (12 heads x 19 tiles = 228 workgroups: 28.5 slots per XCD) 8 heads are read by one XCD and 4 by
-// two: 1.33x the K / V bytes instead of 1.47x with contiguous chunks; with two samples per launch (456 workgroups =
-// 57 slots = exactly 3 pairs per XCD) every slab is fetched once.
-__device__ __forceinline__ void r64_place(int nwg, int Q, int xcd, int jx, int& bh, int& qt) {
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int f = q8 / Q;
+__global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // Workgroup -> (batch * head, query tile), XCD-aware (placement affects speed only): workgroups bid and bid + 8 share an
+  // XCD and its L2.  Every query tile of a (batch, head) pair streams the same K / V slab, so a pair's tiles should sit
+  // on ONE XCD: each XCD first takes f = floor(slots / q_tiles) whole pairs; the pairs left over fill the XCDs'
+  // remaining slots in the order 0,4,1,5,2,6,3,7 -- the round-robin gives the first (nwg & 7) XCDs one slot more, so
+  // this order pairs a larger remainder with a smaller one and a split pair spans two XCDs, not three.  At the
+  // rollout's shape (12 heads x 19 tiles = 228 workgroups: 28.5 slots per XCD) 8 heads are read by one XCD and 4 by
+  // two: 1.33x the K / V bytes instead of 1.47x with contiguous chunks; with two samples per launch (456 workgroups =
+  // 57 slots = exactly 3 pairs per XCD) every slab is fetched once.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, jx = bid >> 3, q8 = nwg >> 3, r8 = nwg & 7;
+  const int Q = p.q_tiles, f = q8 / Q;
+  int bh, qt;
   if (jx < f * Q) {
     bh = xcd * f + jx / Q;
     qt = jx - (jx / Q) * Q;
@@ -675,21 +678,11 @@ __device__ __forceinline__ void r64_place(int nwg, int Q, int xcd, int jx, int& 
     bh = 8 * f + g / Q;
     qt = g - (g / Q) * Q;
   }
-}
-
-// One (pair, key segment) through the assembly body: query tile `qt` of (batch * head) `bh` against key tiles
-// [t0, t1) of its slab.  `part` == nullptr: the whole key range, normalised bf16 output; else the segment's partial
-// result goes to the slot `part` (fp32 O, m, l), to be merged with the pair's other segments.
-__device__ __forceinline__ void r64_segment(const AttP& p, int bh, int qt, int t0, int t1, float* part, char* smem) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = bh / p.H, head = bh - b * p.H;
   const bf16_t* qbase = p.q + (long)b * p.q_bstride + head * HD;
-  const bf16_t* kbase = p.k + (long)b * p.kv_bstride + head * HD + (long)t0 * KT * p.kv_stride;
-  const bf16_t* vbase = p.v + (long)b * p.kv_bstride + head * HD + (long)t0 * KT * p.kv_stride;
+  const bf16_t* kbase = p.k + (long)b * p.kv_bstride + head * HD;
+  const bf16_t* vbase = p.v + (long)b * p.kv_bstride + head * HD;
   bf16_t* obase = p.o + (long)b * p.o_bstride + head * HD;
-  const int lk_seg = min(p.Lk, t1 * KT) - t0 * KT;          // keys of this segment (only the slab's last tile is ragged)
 
   const int r32 = lane & 31, hh = lane >> 5;
   const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
@@ -714,20 +707,12 @@ __device__ __forceinline__ void r64_segment(const AttP& p, int bh, int qt, int t
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      const int row = wave * 64 + qb * 32 + r32;             // row of the 256-row tile
-      const int qrow = qt * QT64 + row;
+      const int qrow = qt * QT64 + wave * 64 + qb * 32 + r32;
       const unsigned long long qa = (unsigned long long)(qbase + (long)min(qrow, p.Lq - 1) * p.q_stride + 8 * hh);
-      unsigned long long oa, ma = 0;
-      if (part) {
-        oa = (unsigned long long)(part + (long)row * HD + 4 * hh);
-        ma = (unsigned long long)(part + QT64 * HD + row);
-      } else {
-        oa = (unsigned long long)(obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 4 * hh);
-      }
+      const unsigned long long oa = (unsigned long long)(obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 4 * hh);
       prm[20 + 2 * qb] = (unsigned)qa; prm[21 + 2 * qb] = (unsigned)(qa >> 32);
       prm[24 + 2 * qb] = (unsigned)oa; prm[25 + 2 * qb] = (unsigned)(oa >> 32);
       prm[29 + qb] = qrow < p.Lq ? 1u : 0u;
-      prm[31 + 2 * qb] = (unsigned)ma; prm[32 + 2 * qb] = (unsigned)(ma >> 32);
     }
     prm[28] = 4 * hh;
   }
@@ -735,7 +720,7 @@ __device__ __forceinline__ void r64_segment(const AttP& p, int bh, int qt, int t
 #pragma unroll
   for (int j = 0; j < SF_R64_N_PARAM; ++j) pl[j * 256 + tid] = prm[j];
 
-  const unsigned kv_bytes = (unsigned)(((long)(lk_seg - 1) * p.kv_stride + HD) * 2);
+  const unsigned kv_bytes = (unsigned)(((long)(p.Lk - 1) * p.kv_stride + HD) * 2);
   auto make_srd = [&](const bf16_t* base) {
     const unsigned long long a64 = (unsigned long long)base;
     u32x4 d;
@@ -747,173 +732,25 @@ __device__ __forceinline__ void r64_segment(const AttP& p, int bh, int qt, int t
   };
   const u32x4 k_srd = make_srd(kbase), v_srd = make_srd(vbase);
   const unsigned tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)((long)KT * p.kv_stride * 2));
-  const int ntiles = __builtin_amdgcn_readfirstlane(t1 - t0);
-  const int lk = __builtin_amdgcn_readfirstlane(lk_seg);
+  const int ntiles = __builtin_amdgcn_readfirstlane((p.Lk + KT - 1) / KT);
+  const int lk = __builtin_amdgcn_readfirstlane(p.Lk);
   const unsigned cbits = __builtin_amdgcn_readfirstlane(__float_as_uint(p.scale_log2));
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 4096u);
   const unsigned lds_b = __builtin_amdgcn_readfirstlane(lds_base);
-  const unsigned partial = __builtin_amdgcn_readfirstlane(part ? 1u : 0u);
   const unsigned tid4 = lds_base + 4u * (unsigned)tid;
   asm volatile(SF_R64_ASM_BODY
                :
-               : "s"(k_srd), "s"(v_srd), "s"(tile_bytes), "s"(ntiles), "s"(lk), "s"(cbits), "s"(lds_wave), "v"(tid4), "s"(lds_b), "s"(partial)
+               : "s"(k_srd), "s"(v_srd), "s"(tile_bytes), "s"(ntiles), "s"(lk), "s"(cbits), "s"(lds_wave), "v"(tid4), "s"(lds_b)
                : SF_R64_CLOBBERS);
 }
 
-__global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int bh, qt;
-  r64_place(gridDim.x, p.q_tiles, blockIdx.x & 7, blockIdx.x >> 3, bh, qt);
-  r64_segment(p, bh, qt, 0, (p.Lk + KT - 1) / KT, nullptr, smem);
-}
 
-// ------------------------------------------------------------------------------------------
-// The same kernel over ALL CUs when the (pair, tile) grid leaves some idle (the rollout: 228 workgroups on 256 CUs):
-// "stream-K" over the key range.  The P pairs x T key tiles are one sequence of units (pair-major, pairs in the XCD-
-// aware order above); workgroup w takes units [w c, (w + 1) c), c = ceil(P T / W) <= T, i.e. the tail of one pair's key
-// range and the head of the next (at most two segments).  A segment that does not cover its pair's whole range writes
-// its partial (O, m, l) to a workspace slot and takes a ticket of the pair's counter; the workgroup that draws the
-// last ticket merges the pair's slots (O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M)) and writes the bf16 rows.
-// Publication follows MI355X_MICROARCH.md (inter-workgroup visibility): every storing wave drains its stores, a
-// workgroup barrier, ONE agent-scope release + drain, a relaxed agent-scope ticket; the merging workgroup does ONE
-// agent-scope acquire + drain + barrier before plain loads.  Nobody waits for another workgroup: no ordering or
-// co-residency of workgroups is assumed.
-struct SkP {
-  float* slots;        // [P][SK_MAX_PARTS][SK_SLOT_FLOATS]
-  int* counters;       // [P], zeroed before the launch
-  int P, T, c;
-};
-
-__device__ __forceinline__ void sk_pair(const AttP& p, int P, int s, int& bh, int& qt) {   // s-th pair of the XCD-aware order
-  const int q8 = P >> 3, r8 = P & 7;
-  int x = 0, base = 0;
-  bool found = false;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int n = q8 + (i < r8 ? 1 : 0);
-    if (!found) {
-      if (s < base + n) found = true;
-      else { base += n; x = i + 1; }
-    }
-  }
-  x = min(x, 7);
-  r64_place(P, p.q_tiles, x, s - base, bh, qt);
-}
-
-__global__ __launch_bounds__(256) void attention_r64_sk_kernel(AttP p, SkP k) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  // XCD remap: workgroups of one XCD take consecutive unit ranges = consecutive pairs of that XCD's share of the order
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const long U = (long)k.P * k.T;
-  long u = (long)w * k.c;
-  const long u_end = min(u + k.c, U);
-#pragma unroll 1
-  while (u < u_end) {
-    const int s = (int)(u / k.T);
-    const int t0 = (int)(u - (long)s * k.T);
-    const int t1 = (int)min((long)k.T, t0 + (u_end - u));
-    int bh, qt;
-    sk_pair(p, k.P, s, bh, qt);
-    const bool whole = t0 == 0 && t1 == k.T;
-    // which part of its pair this segment is: the pair's units start in workgroup range first_w
-    const int first_w = (int)(((long)s * k.T) / k.c);
-    const int last_w = (int)((((long)s + 1) * k.T - 1) / k.c);
-    const int nparts = last_w - first_w + 1, part_i = w - first_w;
-    float* slot0 = k.slots + ((long)s * SK_MAX_PARTS) * SK_SLOT_FLOATS;
-    r64_segment(p, bh, qt, t0, t1, whole ? nullptr : slot0 + (long)part_i * SK_SLOT_FLOATS, smem);
-    if (!whole) {
-      // publish this segment's slot (the stores of the assembly body are already drained: it ends every store group with
-      // s_waitcnt vmcnt(0)), take a ticket, and merge if it is the last one
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* flag = reinterpret_cast<int*>(smem);
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = __hip_atomic_fetch_add(k.counters + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = ticket == nparts - 1 ? 1 : 0;
-        if (ticket == nparts - 1) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      }
-      __syncthreads();
-      const bool last = *flag != 0;
-      __syncthreads();
-      if (last) {
-        // per-row weights of the parts -> LDS, then a coalesced pass over the 256 x 128 tile
-        float* wts = reinterpret_cast<float*>(smem) + 64;                 // [256][4]: w_0, w_1, w_2, 1 / L
-        {
-          const int row = tid;
-          float m[SK_MAX_PARTS], l[SK_MAX_PARTS], M = -3.0e38f;
-#pragma unroll
-          for (int i = 0; i < SK_MAX_PARTS; ++i) {
-            m[i] = -3.0e38f; l[i] = 0.f;
-            if (i < nparts) {
-              const float* sl = slot0 + (long)i * SK_SLOT_FLOATS + QT64 * HD;
-              m[i] = sl[row]; l[i] = sl[QT64 + row];
-              M = fmaxf(M, m[i]);
-            }
-          }
-          float L = 0.f, wv[SK_MAX_PARTS];
-#pragma unroll
-          for (int i = 0; i < SK_MAX_PARTS; ++i) {
-            wv[i] = i < nparts ? __builtin_amdgcn_exp2f(m[i] - M) : 0.f;
-            L += l[i] * wv[i];
-          }
-#pragma unroll
-          for (int i = 0; i < SK_MAX_PARTS; ++i) wts[row * 4 + i] = wv[i];
-          wts[row * 4 + 3] = 1.0f / L;
-        }
-        __syncthreads();
-        const int b = bh / p.H, head = bh - b * p.H;
-        bf16_t* obase = p.o + (long)b * p.o_bstride + head * HD;
-#pragma unroll 4
-        for (int it = 0; it < (QT64 * HD) / (256 * 4); ++it) {
-          const int e = (it * 256 + tid) * 4;
-          const int row = e >> 7, col = e & 127;
-          const int qrow = qt * QT64 + row;
-          if (qrow >= p.Lq) continue;
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int i = 0; i < SK_MAX_PARTS; ++i) {
-            if (i < nparts) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(slot0 + (long)i * SK_SLOT_FLOATS + e);
-              const float wi = wts[row * 4 + i];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[j] += v[j] * wi;
-            }
-          }
-          const float inv = wts[row * 4 + 3];
-          bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(acc[j] * inv);
-          *reinterpret_cast<bf16x4*>(obase + (long)qrow * p.o_stride + col) = o;
-        }
-      }
-      __syncthreads();
-    }
-    u += t1 - t0;
-    __syncthreads();
-  }
-}
 
 }  // namespace
 
-extern "C" size_t sf_attention_workspace_bytes(int B, int H, int Lq) {
-  if (B <= 0 || H <= 0 || Lq <= 0) return 0;
-  const long P = (long)((Lq + QT64 - 1) / QT64) * H * B;
-  if (P <= 128 || P >= 256) return 0;                 // the stream-K form only pays (and is only built) for 128 < P < 256
-  return (size_t)(((P * 4 + 255) & ~255L) + P * SK_MAX_PARTS * (long)SK_SLOT_FLOATS * 4);
-}
-
-extern "C" int sf_attention_ws(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
+extern "C" int sf_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
                                int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
-                               int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, int structure,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, int structure, void* stream) {
   SF_CHECK(q && k && v && out, "sf_attention: null tensor");
   SF_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "sf_attention: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
   SF_CHECK(q_stride % 8 == 0 && kv_stride % 8 == 0 && o_stride % 4 == 0, "sf_attention: strides must keep 16-byte row alignment");
@@ -921,7 +758,7 @@ extern "C" int sf_attention_ws(const void* q, const void* k, const void* v, void
   SF_CHECK(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)out % 8 == 0),
            "sf_attention: misaligned tensor");
   SF_CHECK(((long)(Lk - 1) * kv_stride + 128) * 2 < (1L << 31), "sf_attention: one (batch, head) K/V slab must span < 2 GiB");
-  SF_CHECK(structure >= SF_ATTN_AUTO && structure <= SF_ATTN_R64_SK, "sf_attention: unknown structure %d", structure);
+  SF_CHECK(structure >= SF_ATTN_AUTO && structure <= SF_ATTN_W4, "sf_attention: unknown structure %d", structure);
   AttP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)out;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
@@ -930,44 +767,13 @@ extern "C" int sf_attention_ws(const void* q, const void* k, const void* v, void
   p.q_tiles = (Lq + QT - 1) / QT;
   p.scale_log2 = 1.4426950408889634f / sqrtf((float)HD);
   // Structure (SF_ATTN_AUTO): long key sequences that fill the chip run the hand-scheduled 64-rows-per-wave
-  // kernel -- over all 256 CUs with the key range split stream-K fashion when its (pair, tile) grid would leave CUs
-  // idle and the caller provided the workspace --; short ones that fill it (cross-attention: 8 key tiles) the 8-wave
-  // anti-phase kernel (256 query rows per workgroup); small problems the 4-wave one (128 rows, two workgroups per CU).
-  // Every structure is correct for every shape it accepts; the explicit values exist for tests and A/B timing.
+  // kernel; short ones that fill it (cross-attention: 8 key tiles) the 8-wave anti-phase kernel (256 query rows
+  // per workgroup); small problems the 4-wave one (128 rows, two workgroups per CU).  Every structure is correct
+  // for every shape; the explicit values exist for tests and A/B timing.
   const long nwg64 = (long)((Lq + QT64 - 1) / QT64) * H * B;
   const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
-  const int T = (Lk + KT - 1) / KT;
-  const size_t sk_need = sf_attention_workspace_bytes(B, H, Lq);
-  const bool sk_ok = sk_need > 0 && workspace && workspace_bytes >= sk_need && ((uintptr_t)workspace % 256 == 0) && T >= 4;
-  if (structure == SF_ATTN_AUTO) {
+  if (structure == SF_ATTN_AUTO)
     structure = (nwg64 >= 192 && Lk > 1024) ? SF_ATTN_R64 : nwg8 >= 192 ? SF_ATTN_W8 : SF_ATTN_W4;
-    if (structure == SF_ATTN_R64 && sk_ok && T >= SK_MIN_TILES) structure = SF_ATTN_R64_SK;
-  }
-  if (structure == SF_ATTN_R64_SK) {
-    SF_CHECK(sk_ok, "sf_attention: the stream-K structure needs 128 < pairs < 256 (have %ld), >= 4 key tiles and a 256-byte aligned workspace of "
-             "%zu bytes (have %zu)", nwg64, sk_need, workspace ? workspace_bytes : (size_t)0);
-    p.q_tiles = (Lq + QT64 - 1) / QT64;
-    SkP sk;
-    sk.P = (int)nwg64; sk.T = T;
-    const long U = (long)sk.P * T;
-    const int W = 256;
-    sk.c = (int)((U + W - 1) / W);
-    SF_CHECK(2 * sk.c > T && sk.c <= T, "sf_attention: stream-K split out of range (c=%d, T=%d)", sk.c, T);
-    sk.counters = (int*)workspace;
-    sk.slots = (float*)((char*)workspace + (((size_t)sk.P * 4 + 255) & ~(size_t)255));
-    const int grid = (int)((U + sk.c - 1) / sk.c);
-    hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sk.counters, 0, (size_t)sk.P * 4, s);
-    SF_CHECK(e == hipSuccess, "sf_attention: counter reset failed: %s", hipGetErrorString(e));
-    static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent; no other state is kept)
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);
-      attr = true;
-    }
-    hipLaunchKernelGGL(attention_r64_sk_kernel, dim3((unsigned)grid), dim3(256), ATT64_LDS, s, p, sk);
-    SF_HIP_LAUNCH_CHECK("sf_attention");
-    return 0;
-  }
   if (structure == SF_ATTN_R64) {
     p.q_tiles = (Lq + QT64 - 1) / QT64;
     static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent; no other state is kept)
@@ -998,16 +804,9 @@ extern "C" int sf_attention_ws(const void* q, const void* k, const void* v, void
   return 0;
 }
 
-extern "C" int sf_attention_ex(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
-                               int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
-                               int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, int structure, void* stream) {
-  return sf_attention_ws(q, k, v, out, B, H, Lq, Lk, q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride, structure,
-                         nullptr, 0, stream);
-}
-
 extern "C" int sf_attention(const void* q, const void* k, const void* v, void* out, int B, int H, int Lq,
                             int Lk, int64_t q_stride, int64_t q_bstride, int64_t kv_stride,
                             int64_t kv_bstride, int64_t o_stride, int64_t o_bstride, void* stream) {
-  return sf_attention_ws(q, k, v, out, B, H, Lq, Lk, q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride,
-                         SF_ATTN_AUTO, nullptr, 0, stream);
+  return sf_attention_ex(q, k, v, out, B, H, Lq, Lk, q_stride, q_bstride, kv_stride, kv_bstride, o_stride, o_bstride,
+                         SF_ATTN_AUTO, stream);
 }

@@ -141,31 +141,10 @@ def kv_evict(cache: Tensor, sink: int, evict: int, keep: int, scratch: Tensor) -
                             scratch.numel() * scratch.element_size(), stream_handle()), "sf_kv_evict")
 
 
-_ATTN_WS = {}
-
-
-def attention_workspace(q: Tensor) -> Optional[Tensor]:
-    """The stream-K workspace for attention launches of q's shape on the current stream (None where the split never
-    applies); one buffer per (shape, stream): concurrent launches on different streams must not share it."""
-    B, Lq, H, _ = q.shape
-    n = lib().sf_attention_workspace_bytes(B, H, Lq)
-    if n == 0:
-        return None
-    key = (B, H, Lq, q.device, stream_handle())
-    if key not in _ATTN_WS:
-        _ATTN_WS[key] = torch.empty(n, dtype=torch.uint8, device=q.device)
-    return _ATTN_WS[key]
-
-
-def attention(q: Tensor, k: Tensor, v: Tensor, structure: str = "auto", workspace: Optional[Tensor] = None) -> Tensor:
+def attention(q: Tensor, k: Tensor, v: Tensor, structure: str = "auto") -> Tensor:
     """q [B,Lq,H,128], k/v [B,Lk,H,128] (token/batch strides free, [H,D] contiguous) -> [B,Lq,H,128].
-    `structure` ("auto" | "r64" | "r64_sk" | "w8" | "w4") forces a kernel structure (tests / A-B timing); with a
-    `workspace` (`attention_workspace(q)`) "auto" may split the key range over all CUs (sf_attention_ws)."""
-    if structure == "r64_sk" and workspace is None:
-        workspace = attention_workspace(q)
-    if workspace is None:
-        return torch.ops.sf_hip.attention(q, k, v, _lib.ATTN_STRUCTURES[structure])
-    return torch.ops.sf_hip.attention_ws(q, k, v, _lib.ATTN_STRUCTURES[structure], workspace)
+    `structure` ("auto" | "r64" | "w8" | "w4") forces a kernel structure (tests / A-B timing)."""
+    return torch.ops.sf_hip.attention(q, k, v, _lib.ATTN_STRUCTURES[structure])
 
 
 def patchify(x: Tensor) -> Tensor:

@@ -8,7 +8,7 @@ tracing, and is opaque-but-legal to `torch.compile` -- which the reference's sec
 (demo.py:340); a bare ctypes call would be a graph break with unknown side effects.  `ops.py` (per-kernel wrappers),
 `model.py` (the fused forward), `vae.py`, `text_encoder.py` route through these.
 
-    sf_hip::attention(q, k, v, structure) -> out ;  sf_hip::attention_ws(q, k, v, structure, workspace!) -> out
+    sf_hip::attention(q, k, v, structure) -> out
     sf_hip::gemm(a, w, bias?, epilogue, resid?, gate_mod?, gate_e0?, rows_per_group, structure) -> out
     sf_hip::gemm_out(out!, a, w, ...) -> ()                         (caller-provided / aliased output)
     sf_hip::lincomb(tensors[], coefs[]) -> out ;  sf_hip::lincomb_out(out!, tensors[], coefs[]) -> ()
@@ -68,7 +68,8 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 
 
 # ------------------------------------------------------------------------------------------ attention
-def _attention_launch(q: Tensor, k: Tensor, v: Tensor, structure: int, workspace: Optional[Tensor]) -> Tensor:
+@custom_op(f"{NAMESPACE}::attention", mutates_args=())
+def attention(q: Tensor, k: Tensor, v: Tensor, structure: int = 0) -> Tensor:
     for n, t in (("q", q), ("k", k), ("v", v)):
         _need_gpu(t, n)
         if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1 or t.stride(2) != 128:
@@ -77,31 +78,14 @@ def _attention_launch(q: Tensor, k: Tensor, v: Tensor, structure: int, workspace
     if k.stride() != v.stride() or k.shape != v.shape:
         raise ValueError("attention: k and v must share shape and strides")
     out = torch.empty(B, Lq, H, D, dtype=torch.bfloat16, device=q.device)
-    ws_ptr, ws_bytes = (workspace.data_ptr(), workspace.numel() * workspace.element_size()) if workspace is not None else (None, 0)
-    _lib.check(_lib.lib().sf_attention_ws(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Lq, k.shape[1],
+    _lib.check(_lib.lib().sf_attention_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Lq, k.shape[1],
                                           q.stride(1), q.stride(0), k.stride(1), k.stride(0), out.stride(1), out.stride(0),
-                                          structure, ws_ptr, ws_bytes, _stream(q)), "sf_attention")
+                                          structure, _stream(q)), "sf_attention")
     return out
-
-
-@custom_op(f"{NAMESPACE}::attention", mutates_args=())
-def attention(q: Tensor, k: Tensor, v: Tensor, structure: int = 0) -> Tensor:
-    return _attention_launch(q, k, v, structure, None)
 
 
 @attention.register_fake
 def _(q, k, v, structure=0):
-    return q.new_empty(q.shape)
-
-
-@custom_op(f"{NAMESPACE}::attention_ws", mutates_args=("workspace",))
-def attention_ws(q: Tensor, k: Tensor, v: Tensor, structure: int, workspace: Tensor) -> Tensor:
-    """With the stream-K workspace (sf_attention_workspace_bytes): the key range may be split over all CUs."""
-    return _attention_launch(q, k, v, structure, workspace)
-
-
-@attention_ws.register_fake
-def _(q, k, v, structure, workspace):
     return q.new_empty(q.shape)
 
 
@@ -322,4 +306,4 @@ def _(model, ids, mask, buckets, workspace):
     return ids.new_empty((ids.shape[0], ids.shape[1], _model(model).shape.dim), dtype=torch.bfloat16)
 
 
-OPS = ("attention", "attention_ws", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "vae_decode_frame", "t5_encode")
+OPS = ("attention", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "vae_decode_frame", "t5_encode")

@@ -17,7 +17,7 @@ import code_objects as co  # noqa: E402
 # kernels that may hold packed fp32 at all, and in which exact form: the generated instruction stream of the
 # 64-row attention kernel scales O by exp2(m_old - m_new) with plain v_pk_mul_f32 in its (rare) rescale path; its
 # waves own their SIMD's whole register file (one wave per SIMD) and never run beside another wave's MFMAs.
-ALLOWED = {"attention_r64_kernel": {"v_pk_mul_f32"}, "attention_r64_sk_kernel": {"v_pk_mul_f32"}}   # (same assembly body)
+ALLOWED = {"attention_r64_kernel": {"v_pk_mul_f32"}}
 
 
 def _lib_path():

@@ -301,59 +301,6 @@ def test_attention_r64_long_sequences_vs_fp32(H, Lq, Lk, kind):
     assert torch.equal(out, ops.attention(q.to(DEV), k.to(DEV), v.to(DEV)))
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,kind", [
-    (1, 12, 4680, 32760, "random"), (1, 12, 4680, 32760, "drift"), (1, 12, 4680, 18720, "drift"), (1, 12, 4680, 9360, "random"),
-    (1, 12, 4680, 65520, "drift"),
-    (1, 8, 4100, 1000, "random"),     # 17 tiles x 8 heads = 136 pairs, 16 key tiles: segments of 8-9 tiles, ragged last tile
-    (2, 5, 3600, 2049, "drift"),      # batch 2: 15 x 10 = 150 pairs; Lk one key past a tile
-    (1, 12, 4680, 300, "random"),     # 5 key tiles: segments of 4-5 tiles
-])
-def test_attention_stream_k_split(B, H, Lq, Lk, kind):
-    """The 64-row kernel over all 256 CUs with the key range split stream-K fashion (SF_ATTN_R64_SK): every workgroup runs
-    at most two (pair, key segment) pieces; partial (O, m, l) of a split pair go through the workspace and are merged
-    by the workgroup that draws the pair's last ticket.  Against fp32 softmax(QK^T)V on a row subset of every head
-    (same bounds as the unsplit kernel), against the unsplit kernel (summation order differs: close, not equal), and
-    bit-for-bit against itself over repeated launches (which workgroup merges depends on timing; what it computes
-    must not)."""
-    g = torch.Generator().manual_seed(B + H + Lq + Lk)
-    q, k, v = bf((B, Lq, H, 128), g), bf((B, Lk, H, 128), g, 0.5), bf((B, Lk, H, 128), g)
-    if kind == "drift":
-        ramp = torch.linspace(0.5, 2.0, Lk).view(1, Lk, 1, 1)
-        k = (k.float() * ramp).to(torch.bfloat16)
-        for j, pos in enumerate(range(Lk // 3, Lk - 5, max(1, Lk // 9))):
-            k[0, pos, j % H] = (q[0, (977 * j + 13) % Lq, j % H].float() * 4).to(torch.bfloat16)
-            k[B - 1, pos + 3, (j + 1) % H] = (q[B - 1, Lq - 1 - j, (j + 1) % H].float() * 4).to(torch.bfloat16)
-    rows = _row_subset(Lq, 97)
-    ref = wo.sdpa(q[:, rows].float(), k.float(), v.float())
-    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    ws = ops.attention_workspace(qd)
-    assert ws is not None
-    ws.fill_(0x7F)                                       # stale bytes in the workspace must not matter
-    out = ops.attention(qd, kd, vd, structure="r64_sk", workspace=ws)
-    torch.cuda.synchronize()
-    assert torch.isfinite(out.float()).all()
-    got = out[:, rows.to(DEV)].float().cpu()
-    assert rel(got, ref) < 6e-3, rel(got, ref)
-    rms = ref.pow(2).mean().sqrt().item()
-    assert ((got - ref).abs() <= 1.2e-2 * ref.abs() + 0.05 * rms).all()
-    for h in range(H):
-        assert rel(got[:, :, h], ref[:, :, h]) < 8e-3, h
-    plain = ops.attention(qd, kd, vd, structure="r64")
-    assert rel(out, plain) < 3e-3
-    for _ in range(5):
-        assert torch.equal(ops.attention(qd, kd, vd, structure="r64_sk", workspace=ws), out)
-    if Lk >= 8192 and B == 1:                            # what the automatic choice takes once a workspace is offered
-        assert torch.equal(ops.attention(qd, kd, vd, workspace=ws), out)
-        assert torch.equal(ops.attention(qd, kd, vd), plain)
-
-
-def test_attention_stream_k_rejects_shapes_it_cannot_split():
-    q = torch.zeros(1, 512, 2, 128, dtype=torch.bfloat16, device=DEV)      # 2 x 2 = 4 pairs: nothing to split
-    assert ops.attention_workspace(q) is None
-    with pytest.raises(sfa._lib.SfHipError, match="stream-K"):
-        ops.attention(q, q, q, structure="r64_sk")
-
-
 def test_attention_online_softmax_rescale_branch():
     """Force the running max to jump late: one key far along the sequence dominates one query
     (cdna guide rule 26: a rescale branch needs an input that takes it)."""

@@ -48,7 +48,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
                    "attention_r64_asm.inc")
 
 # ---- inline-asm operands (inputs only)
-K_SRD, V_SRD, TILE_BYTES, NTILES, LK, CSCALE, LDS_WAVE, TID4, LDS_BASE, PARTIAL = "%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8", "%9"
+K_SRD, V_SRD, TILE_BYTES, NTILES, LK, CSCALE, LDS_WAVE, TID4, LDS_BASE = "%0", "%1", "%2", "%3", "%4", "%5", "%6", "%7", "%8"
 
 # ---- register map
 KADDR = [1 + i for i in range(8)]
@@ -58,7 +58,6 @@ DMAOFF = [17 + i for i in range(4)]
 QP = [22, 24]
 OP = [26, 28]
 HH4, VALID = 30, [31, 32]
-ML = [50, 52]         # partial results (split key range): per-lane address of the row's m; l sits 1024 bytes behind it
 KCUR = [33 + i for i in range(8)]
 VCURLO = [41 + i for i in range(4)]
 VCURHI = [45 + i for i in range(4)]
@@ -74,7 +73,7 @@ NEG = 254
 A_O = lambda qb, db: (qb * 4 + db) * 16          # noqa: E731
 A_Q = lambda qb, s: 128 + (qb * 8 + s) * 4       # noqa: E731
 KF, VF = 192, 224     # AGPR fragment slots
-N_PARAM = 35
+N_PARAM = 31
 
 ST, NTM1, KS_CUR, KS_N1, KS_N2, KS_DMA, VS_CUR, VS_N1, VS_DMA, STMP = 60, 61, 62, 63, 64, 65, 66, 67, 68, 69
 C2, SEXEC, SOFFK, SOFFV, SLIM, STMP2 = 70, 72, 74, 75, 76, 77
@@ -423,8 +422,7 @@ def body(kind):
 
 def main():
     e("; ---- parameters handed over through LDS: dword j of lane tid at byte j*1024 + tid*4")
-    dst = (KADDR + VLO + VHI + DMAOFF + [QP[0], QP[0] + 1, QP[1], QP[1] + 1, OP[0], OP[0] + 1, OP[1], OP[1] + 1, HH4] + VALID
-           + [ML[0], ML[0] + 1, ML[1], ML[1] + 1])
+    dst = KADDR + VLO + VHI + DMAOFF + [QP[0], QP[0] + 1, QP[1], QP[1] + 1, OP[0], OP[0] + 1, OP[1], OP[1] + 1, HH4] + VALID
     assert len(dst) == N_PARAM
     for j, d in enumerate(dst):
         e(f"ds_read_b32 {vr(d)}, {TID4} offset:{j * 1024}")
@@ -520,21 +518,17 @@ def main():
     body("penult")
     e(f"{last_l}:")
     body("last")
-    e("; ---- epilogue: O / l -> bf16, rows past Lq masked off; or, for a SEGMENT of the key range (PARTIAL != 0), the")
-    e(";      unnormalised fp32 O^T accumulators + the row's reference m c (log2 units) + its l, merged later")
+    e("; ---- epilogue: O / l -> bf16, rows past Lq masked off")
     e("s_nop 7")
     e("s_nop 7")
     e("s_nop 7")
     for qb in range(2):
-        part_l, done_l = f".Lr64_part{qb}%=", f".Lr64_done{qb}%="
         e(f"v_add_f32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(L2[qb] + 1)}")
         e(f"v_mov_b32 {vr(TMP)}, {vr(L2[qb])}")
         e("s_nop 0")
         e(f"v_permlane32_swap_b32 {vr(L2[qb])}, {vr(TMP)}")
         e("s_nop 0")
         e(f"v_add_f32 {vr(L2[qb])}, {vr(L2[qb])}, {vr(TMP)}")
-        e(f"s_cmp_lg_u32 {PARTIAL}, 0")
-        e(f"s_cbranch_scc1 {part_l}")
         e(f"v_rcp_f32 {vr(DLT[0])}, {vr(L2[qb])}")
         e("s_nop 1")
         e(f"v_cmp_ne_u32 vcc, 0, {vr(VALID[qb])}")
@@ -553,30 +547,13 @@ def main():
                 e(f"global_store_dwordx2 {vr(OP[qb], 2)}, {vr(S[1] + 2 * rg, 2)}, off offset:{db * 64 + rg * 16}")
             e("s_waitcnt vmcnt(0)")
         e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
-        e(f"s_branch {done_l}")
-        e(f"{part_l}:")
-        e(f"v_cmp_ne_u32 vcc, 0, {vr(VALID[qb])}")
-        e(f"s_and_saveexec_b64 s[{SEXEC}:{SEXEC + 1}], vcc")
-        e(f"global_store_dword {vr(ML[qb], 2)}, {vr(MRC[qb])}, off")
-        e(f"global_store_dword {vr(ML[qb], 2)}, {vr(L2[qb])}, off offset:1024")
-        for db in range(4):
-            for i in range(16):
-                e(f"v_accvgpr_read_b32 {vr(S[0] + i)}, {ar(A_O(qb, db) + i)}")
-            e("s_nop 1")
-            for rg in range(4):
-                # accumulators 4 rg .. 4 rg + 3 of block db = O^T[d = 32 db + 8 rg + 4 hh + j][query]: 16 bytes of the row
-                e(f"global_store_dwordx4 {vr(OP[qb], 2)}, {vr(S[0] + 4 * rg, 4)}, off offset:{db * 128 + rg * 32}")
-            e("s_waitcnt vmcnt(0)")
-        e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
-        e(f"{done_l}:")
     end_l = ".Lr64_end%="
     e(f"s_branch {end_l}")
     for ln in cold:
         e(ln)
     e(f"{end_l}:")
     body_txt = "\n".join('    "' + ln.replace("\n\t", '\\n\\t') + '\\n"' for ln in out)
-    # v200-v239 are not used by the body: left to the compiler (a caller that loops over segments keeps its state there)
-    clob_v = ", ".join(f'"v{i}"' for i in range(1, 256) if not 200 <= i <= 239)
+    clob_v = ", ".join(f'"v{i}"' for i in range(1, 256))
     clob_a = ", ".join(f'"a{i}"' for i in range(0, 256))
     clob_s = ", ".join(f'"s{i}"' for i in range(60, 80))
     path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT

@@ -33,7 +33,6 @@ def main():
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--vae-frames", type=int, default=21)
     ap.add_argument("--batch", type=int, default=1, help="samples per attention launch")
-    ap.add_argument("--attn-structures", default="auto", help="attention structures to time, e.g. r64,r64_sk")
     ap.add_argument("--structures", default="auto", help="GEMM tilings to time, e.g. auto,t128,pp256,pp128")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved timing rounds per (shape, structure); the best is printed")
     a = ap.parse_args()
@@ -45,16 +44,9 @@ def main():
         for lk in [int(x) for x in a.lk.split(",")]:
             k = torch.randn(a.batch, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
             v = torch.randn(a.batch, lk, a.heads, 128, generator=g).to(torch.bfloat16).to(dev)
+            ms = timeit(lambda: ops.attention(q, k, v), a.iters)
             fl = 4.0 * C * a.n * lk * a.batch
-            sts = a.attn_structures.split(",")
-            best = {st: 1e9 for st in sts}
-            ws = ops.attention_workspace(q)
-            for rnd in range(a.rounds):
-                for st in (sts if rnd % 2 == 0 else sts[::-1]):
-                    best[st] = min(best[st], timeit(lambda: ops.attention(q, k, v, structure=st, workspace=ws if st == "r64_sk" else None), a.iters))
-            for st in sts:
-                ms = best[st]
-                print(f"attention B={a.batch} N={a.n} Lk={lk} H={a.heads} {st:6s}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+            print(f"attention B={a.batch} N={a.n} Lk={lk} H={a.heads}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
     if "t5" in a.what:
         bench_t5(max(2, a.iters // 2))
     if "vae" in a.what:
