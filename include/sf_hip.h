@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 5
+#define SF_HIP_ABI_VERSION 6
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -275,7 +275,12 @@ typedef struct sf_conv_args {
   int32_t interleave_c;   /* > 0 (= Cout/2): channel n of output frame t goes to frame 2t + n/interleave_c,
                              channel n % interleave_c (t' above)                                   */
   int32_t epilogue;       /* enum sf_conv_epilogue */
+  int32_t structure;      /* enum sf_conv_structure: 0 = picked from the shape; the others force a kernel (tests, A/B timing) */
 } sf_conv_args;
+
+enum sf_conv_structure { SF_CONV_AUTO = 0, SF_CONV_IGEMM = 1 /* A tile gathered per tap (every shape) */,
+                         SF_CONV_HALO = 2 /* 16 x 16 output patch, input halo staged once per (channel slice, frame):
+                                             3 x 3 spatial taps, Cout % 96 == 0, bf16 bias / bias + residual */ };
 
 int sf_conv_igemm(const sf_conv_args* args, void* stream);
 int sf_conv_pick_nt(int cout);   /* column tiles (of 16) per wave the launcher will use for Cout    */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # epilogue codes (enum sf_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
@@ -23,6 +23,7 @@ VAE_MAX_STAGES = 4
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 # enum sf_attn_structure / sf_gemm_structure
 ATTN_STRUCTURES = {"auto": 0, "r64": 1, "w8": 2, "w4": 3}
+CONV_STRUCTURES = {"auto": 0, "igemm": 1, "halo": 2}
 GEMM_STRUCTURES = {"auto": 0, "t128": 1, "pp256": 2, "pp128": 3}
 
 
@@ -85,7 +86,7 @@ class ConvArgs(C.Structure):
     _fields_ = (
         [(n, C.c_void_p) for n in ("x", "w", "bias", "out", "resid", "out_f32")]
         + [(n, C.c_int32) for n in ("Tout", "H", "W", "Hin", "Win", "Cin", "Cout", "kt", "kh", "kw", "upsample",
-                                    "t_in_offset", "ldw", "ldo", "ldr", "out_frame_offset", "interleave_c", "epilogue")]
+                                    "t_in_offset", "ldw", "ldo", "ldr", "out_frame_offset", "interleave_c", "epilogue", "structure")]
     )
 
 

@@ -393,8 +393,11 @@ extern "C" int sf_conv_pick_nt(int cout) {
   return best;
 }
 
+int sf_conv_halo_launch(const sf_conv_args* a, void* stream);   // conv_halo.hip: 1 = outside its domain
+
 extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
   SF_CHECK(a != nullptr, "sf_conv_igemm: null args");
+  SF_CHECK(a->structure >= SF_CONV_AUTO && a->structure <= SF_CONV_HALO, "sf_conv_igemm: unknown structure %d", a->structure);
   SF_CHECK(a->x && a->w && a->bias, "sf_conv_igemm: null tensor");
   SF_CHECK(a->Tout > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, "sf_conv_igemm: empty problem");
   SF_CHECK(a->Cin % 32 == 0, "sf_conv_igemm: Cin=%d must be a multiple of 32 (pad the channels)", a->Cin);
@@ -419,6 +422,18 @@ extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
     SF_CHECK(a->ldo >= (a->interleave_c ? a->interleave_c : a->Cout), "sf_conv_igemm: ldo too small");
     if (a->epilogue == SF_CONV_BIAS_RESID)
       SF_CHECK(a->resid != nullptr && a->ldr % 4 == 0 && a->ldr >= a->Cout && a->interleave_c == 0, "sf_conv_igemm: residual epilogue needs resid/ldr");
+  }
+  if (a->structure != SF_CONV_IGEMM) {
+    // 3 x 3 convolutions with 96 k / 192 k output channels: the halo-tile kernel (the A operand staged once per
+    // (channel slice, frame) instead of once per tap), conv_halo.hip
+    const int rc = sf_conv_halo_launch(a, stream);
+    SF_CHECK(rc >= 0, "sf_conv_igemm: halo kernel failed");
+    SF_CHECK(rc == 0 || a->structure == SF_CONV_AUTO, "sf_conv_igemm: the halo structure needs 3x3 spatial taps, Cout %% 96 == 0, H, W >= 16, "
+             "a bf16 bias / bias + residual epilogue and no interleave");
+    if (rc == 0) {
+      SF_HIP_LAUNCH_CHECK("sf_conv_igemm");
+      return 0;
+    }
   }
   ConvP p;
   p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = (const bf16_t*)a->bias;

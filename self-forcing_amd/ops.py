@@ -200,7 +200,7 @@ def lincomb(tensors, coefs, out: Optional[Tensor] = None) -> Tensor:
 # VAE decode kernels (channels-last bf16 volumes)
 def conv_igemm(x: Tensor, w_packed: Tensor, bias: Tensor, kernel, t_out: int, upsample: bool = False,
                t_in_offset: int = 0, resid: Optional[Tensor] = None, interleave: bool = False,
-               clamp_f32: bool = False, cin: Optional[int] = None) -> Tensor:
+               clamp_f32: bool = False, cin: Optional[int] = None, structure: str = "auto") -> Tensor:
     """Implicit-GEMM convolution (sf_conv_igemm).  x [Tin, Hin, Win, Cin] channels-last with the history
     frames in front; w_packed from `vae.repack_conv`; kernel = (kt, kh, kw).  Returns [Tout, H, W, Cout]
     bf16 -- [2 Tout, H, W, Cout/2] with `interleave` -- or float32 [Tout, Cout, H, W] with `clamp_f32`."""
@@ -218,6 +218,7 @@ def conv_igemm(x: Tensor, w_packed: Tensor, bias: Tensor, kernel, t_out: int, up
     a.Tout, a.H, a.W, a.Hin, a.Win = t_out, H, W, hin, win
     a.Cin, a.Cout, a.kt, a.kh, a.kw = cin or c, cout, kt, kh, kw
     a.upsample, a.t_in_offset, a.ldw = int(upsample), t_in_offset, w_packed.stride(0)
+    a.structure = _lib.CONV_STRUCTURES[structure]
     if clamp_f32:
         out = torch.empty(t_out, cout, H, W, dtype=torch.float32, device=x.device)
         a.out_f32, a.epilogue = out.data_ptr(), CONV_BIAS_CLAMP_F32

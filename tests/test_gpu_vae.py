@@ -49,6 +49,52 @@ def test_conv3d_causal_with_history(cin, cout, T, H, W):
     assert rel(out.float().permute(3, 0, 1, 2), ref) < 4e-3
 
 
+@pytest.mark.parametrize("cin,cout,T,H,W,resid", [(96, 96, 2, 32, 48, False), (96, 96, 1, 23, 37, True), (192, 192, 2, 16, 16, True),
+                                                  (192, 384, 1, 20, 33, False), (384, 192, 3, 17, 16, False), (32, 96, 4, 40, 24, True)])
+def test_conv3d_halo_structure(cin, cout, T, H, W, resid):
+    """The halo-tile kernel (16 x 16 output patches, the 18 x 18 input halo staged once per channel slice and frame, the
+    taps as shifted fragment reads): full and ragged patches (H, W not multiples of 16), both channel configurations
+    (Cout % 192 == 0: one tap per cluster; Cout = 96: a kernel row per cluster), 1 .. 12 channel slices, the residual
+    epilogue; against fp32 conv3d and against the gather-per-tap kernel (different summation order: close, not equal)."""
+    g = torch.Generator().manual_seed(cin + cout + T + H)
+    x = bf((cin, T + 2, H, W), g)
+    w, b = bf((cout, cin, 3, 3, 3), g, (27 * cin) ** -0.5), bf((cout,), g, 0.1)
+    r = bf((T, H, W, cout), g) if resid else None
+    ref = F.conv3d(F.pad(x.float()[None], (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+    if resid:
+        ref = ref + r.float()
+    xd, wd, bd, rd = cl(x).to(DEV), repack_conv(w).to(DEV), b.to(DEV), (r.to(DEV) if resid else None)
+    out = ops.conv_igemm(xd, wd, bd, (3, 3, 3), T, resid=rd, structure="halo")
+    assert out.shape == (T, H, W, cout)
+    assert rel(out.float(), ref) < 4e-3
+    old = ops.conv_igemm(xd, wd, bd, (3, 3, 3), T, resid=rd, structure="igemm")
+    assert rel(out.float(), old.float()) < 3e-3
+    assert torch.equal(out, ops.conv_igemm(xd, wd, bd, (3, 3, 3), T, resid=rd))          # the automatic choice
+    for _ in range(3):                                                                    # counted waits: repeatable
+        assert torch.equal(out, ops.conv_igemm(xd, wd, bd, (3, 3, 3), T, resid=rd, structure="halo"))
+
+
+@pytest.mark.parametrize("cin,cout,T,h,w_", [(192, 96, 2, 16, 24), (384, 192, 1, 9, 13), (96, 96, 3, 8, 8)])
+def test_conv2d_upsample_halo_structure(cin, cout, T, h, w_):
+    """Per-frame 3 x 3 convolution behind the fused nearest 2x upsampling in the halo kernel (10 x 10 input halo)."""
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = bf((T, cin, h, w_), g)
+    w, b = bf((cout, cin, 3, 3), g, (9 * cin) ** -0.5), bf((cout,), g, 0.1)
+    up = F.interpolate(x.float(), scale_factor=(2.0, 2.0), mode="nearest")
+    ref = F.conv2d(up, w.float(), b.float(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = ops.conv_igemm(xd, repack_conv(w).to(DEV), b.to(DEV), (1, 3, 3), T, upsample=True, structure="halo")
+    assert out.shape == (T, 2 * h, 2 * w_, cout)
+    assert rel(out.float().permute(0, 3, 1, 2), ref) < 4e-3
+
+
+def test_conv_halo_rejects_what_it_cannot_do():
+    x = torch.zeros(3, 20, 20, 64, dtype=torch.bfloat16, device=DEV)
+    w = repack_conv(torch.zeros(64, 64, 3, 3, 3, dtype=torch.bfloat16)).to(DEV)
+    with pytest.raises(sfa._lib.SfHipError, match="halo"):
+        ops.conv_igemm(x, w, torch.zeros(64, dtype=torch.bfloat16, device=DEV), (3, 3, 3), 1, structure="halo")     # Cout = 64
+
+
 def test_conv3d_residual_and_1x1():
     g = torch.Generator().manual_seed(5)
     cin, cout, T, H, W = 64, 96, 2, 7, 9

@@ -51,6 +51,8 @@ def main():
         bench_t5(max(2, a.iters // 2))
     if "vae" in a.what:
         bench_vae(a.vae_frames, max(1, a.iters // 5))
+    if "conv" in a.what:
+        bench_conv(a.iters, a.rounds)
     if "gemm" in a.what:
         for (N, K, epi) in [(3 * C, C, "bias"), (C, C, "resid"), (8960 if C == 1536 else 13824, C, "gelu"),
                             (C, 8960 if C == 1536 else 13824, "resid")]:
@@ -86,6 +88,23 @@ def bench_t5(iters):
     ms = timeit(lambda: enc.encode_ids(ids, mask), iters)
     fl = 24 * (4 * 2.0 * 512 * 4096 * 4096 + 3 * 2.0 * 512 * 4096 * 10240 + 4.0 * 512 * 512 * 4096)
     print(f"umT5-XXL encode, 1 prompt x 512 tokens: {ms:8.2f} ms  {fl / ms / 1e9:7.1f} TFLOP/s ({fl / 1e12:.2f} TFLOP)", flush=True)
+
+
+def bench_conv(iters, rounds):
+    """The VAE decoder's big 3 x 3 x 3 convolutions at their real sizes (T = 4 output frames), both kernels."""
+    from self_forcing_amd.vae import repack_conv
+    g = torch.Generator().manual_seed(0)
+    for (cin, cout, T, H, W) in [(96, 96, 4, 480, 832), (192, 192, 4, 240, 416), (384, 384, 2, 120, 208), (192, 96, 4, 480, 832)]:
+        x = torch.randn(T + 2, H, W, cin, generator=g).to(torch.bfloat16).cuda()
+        w = repack_conv((torch.randn(cout, cin, 3, 3, 3, generator=g) * (27 * cin) ** -0.5).to(torch.bfloat16)).cuda()
+        b = torch.zeros(cout, dtype=torch.bfloat16, device="cuda")
+        fl = 2.0 * T * H * W * cout * 27 * cin
+        best = {"igemm": 1e9, "halo": 1e9}
+        for rnd in range(max(1, rounds)):
+            for st in (("igemm", "halo") if rnd % 2 == 0 else ("halo", "igemm")):
+                best[st] = min(best[st], timeit(lambda: ops.conv_igemm(x, w, b, (3, 3, 3), T, structure=st), max(2, iters // 2)))
+        for st, ms in best.items():
+            print(f"conv3x3x3 Cin={cin} Cout={cout} T={T} {H}x{W} {st:5s}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
 def bench_vae(frames, iters):
