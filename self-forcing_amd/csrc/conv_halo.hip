@@ -135,21 +135,29 @@ __global__ __launch_bounds__(HALO_THREADS) void conv_halo_kernel(HaloP p) {
     }
   };
 
-  // ---- fragment read addresses
+  // ---- fragment read addresses.  Everything that depends on the tap is tabulated ONCE per lane (9 taps x 4 row tiles =
+  // 36 registers): computed per cluster the shifts, the upsampling's halving and the swizzle were ~200 VALU / SALU
+  // instructions in front of every cluster's reads, three times the cluster's own MFMA time.
   const int i16 = lane & 15, kq = lane >> 4;
   int w_frag[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = wn * 16 * NT + nt * 16 + i16;
-    w_frag[nt] = n * 64 + swz16(n, kq);
+    w_frag[nt] = W_BASE + n * 64 + swz16(n, kq);
   }
-  auto a_addr = [&](int mt, int dh, int dw) __attribute__((always_inline)) {
-    const int r = wm * 4 + mt;
-    const int hr = p.up ? ((r + dh - 1) >> 1) + 1 : r + dh;
-    const int wc = p.up ? ((i16 + dw - 1) >> 1) + 1 : i16 + dw;
-    const int pos = hr * PW + wc;
-    return pos * 64 + swz16(pos, kq);
-  };
+  int a_tab[9][4];
+#pragma unroll
+  for (int st = 0; st < 9; ++st) {
+    const int dh = st / 3, dw = st - 3 * dh;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int r = wm * 4 + mt;
+      const int hr = p.up ? ((r + dh - 1) >> 1) + 1 : r + dh;
+      const int wc = p.up ? ((i16 + dw - 1) >> 1) + 1 : i16 + dw;
+      const int pos = hr * PW + wc;
+      a_tab[st][mt] = pos * 64 + swz16(pos, kq);
+    }
+  }
 
   f32x4 acc[4][NT];
 #pragma unroll
@@ -158,67 +166,77 @@ __global__ __launch_bounds__(HALO_THREADS) void conv_halo_kernel(HaloP p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[TPC][4], wf[TPC][NT];
 
-  const int NPL = p.cpt * p.kt;              // planes
-  const int NQ = NPL * CPP;                  // clusters
-  // prologue: planes 0, 1 and the weights of clusters 0, 1
+  const int NPL = p.cpt * p.kt;              // planes: (channel slice, temporal tap), slice-major
+  // prologue: planes 0, 1 and the weights of clusters 0, 1 (both in plane 0: a plane has CPP >= 3 clusters)
   request_plane(0);
   if (NPL > 1) request_plane(1);
   request_weights(0, 0, 0);
-  request_weights(1, TPC, 0);                // cluster 1 is in plane 0 too (CPP >= 3): its taps start at TPC
+  request_weights(1, TPC, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
-  int P = 0, c_in_plane = 0;                 // cluster q: plane P, cluster c_in_plane of it
-  for (int q = 0; q < NQ; ++q) {
-    // ---------------- load segment
-    const int cs = P / p.kt, dt = P - cs * p.kt;
+  // weight k-offset (elements) of a plane's first tap: (dt * 9) * Cin + cs * 32; cursors of this plane and the next
+  int cs_n = 0, dt_n = 1;                    // (cs, dt) of plane P + 1
+  if (dt_n == p.kt) { dt_n = 0; cs_n = 1; }
+  long k_cur = 0, k_nxt = (long)dt_n * 9 * p.Cin + cs_n * 32;
+  for (int P = 0; P < NPL; ++P) {
     const char* plane = smem + (P & (PLANE_RING - 1)) * PLANE_SLOT;
-    const char* wring = smem + W_BASE + (q % 3) * W_CLUSTER;
-    const int tap_in_plane0 = c_in_plane * TPC;          // spatial tap index 0..8 of the cluster's first tap
+    const bool more_plane = P + 2 < NPL, next_plane = P + 1 < NPL;
 #pragma unroll
-    for (int ti = 0; ti < TPC; ++ti) {
-      const int st = tap_in_plane0 + ti;
-      const int dh = (st * 11) >> 5, dw = st - 3 * dh;
+    for (int c = 0; c < CPP; ++c) {          // cluster q = P * CPP + c; CPP % 3 == 0, so its weight ring slot is c % 3
+      // ---------------- load segment
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[ti][mt] = *reinterpret_cast<const bf16x8*>(plane + a_addr(mt, dh, dw));
+      for (int ti = 0; ti < TPC; ++ti) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wf[ti][nt] = *reinterpret_cast<const bf16x8*>(wring + ti * W_TAP + w_frag[nt]);
-    }
-    int issued = 0;
-    if (c_in_plane == 0 && P + 2 < NPL) { request_plane(P + 2); issued += 3; }
-    if (q + 2 < NQ) {
-      // position of cluster q + 2 in the (slice, temporal tap, spatial tap) order
-      int P2 = P, c2 = c_in_plane + 2;
-      if (c2 >= CPP) { c2 -= CPP; ++P2; }
-      const int cs2 = P2 / p.kt, dt2 = P2 - cs2 * p.kt;
-      request_weights(q + 2, dt2 * 9 + c2 * TPC, cs2);
-      issued += WPW;
-    }
-    // everything requested before this segment has landed: the next cluster's weights and planes
-    if (issued == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (issued == WPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
-    else if (issued == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 3) : "memory");
-    __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's fragment reads are retired
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- MFMA cluster
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ti = 0; ti < TPC; ++ti)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) af[ti][mt] = *reinterpret_cast<const bf16x8*>(plane + a_tab[c * TPC + ti][mt]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ti][nt], af[ti][mt], acc[mt][nt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    (void)cs; (void)dt;
-    if (++c_in_plane == CPP) { c_in_plane = 0; ++P; }
+          wf[ti][nt] = *reinterpret_cast<const bf16x8*>(smem + (c % 3) * W_CLUSTER + ti * W_TAP + w_frag[nt]);
+      }
+      const bool req_plane = c == 0 && more_plane;
+      if (req_plane) request_plane(P + 2);
+      // weights of cluster q + 2: two clusters further in this plane, or in the next one
+      const bool req_w = c + 2 < CPP || next_plane;
+      if (req_w) {
+        const long koff = c + 2 < CPP ? k_cur + (long)(c + 2) * TPC * p.Cin : k_nxt + (long)(c + 2 - CPP) * TPC * p.Cin;
+        char* ring = smem + W_BASE + ((c + 2) % 3) * W_CLUSTER;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+          char* dst = w_dst[i] >= 0 ? ring + w_dst[i] : smem + DUMMY + wave * 1024;
+          __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + koff), (lptr_t)dst, 16, 0, 0);
+        }
+      }
+      // everything requested BEFORE this segment has landed: the next cluster's weights, the next plane
+      if (req_plane) {
+        if (req_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 3) : "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        if (req_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): this wave's fragment reads are retired
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- MFMA cluster
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ti = 0; ti < TPC; ++ti)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ti][nt], af[ti][mt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // advance the plane cursors
+    k_cur = k_nxt;
+    if (++dt_n == p.kt) { dt_n = 0; ++cs_n; }
+    k_nxt = (long)dt_n * 9 * p.Cin + cs_n * 32;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
 
