@@ -276,6 +276,12 @@ typedef struct sf_conv_args {
                              channel n % interleave_c (t' above)                                   */
   int32_t epilogue;       /* enum sf_conv_epilogue */
   int32_t structure;      /* enum sf_conv_structure: 0 = picked from the shape; the others force a kernel (tests, A/B timing) */
+  /* Optional second output of the SF_CONV_HALO kernel with Cout = 96 or 192 (all channels in one tile): the NEXT
+   * convolution's input, SiLU(RMS_norm(y) * gamma) (vae.py:41-56, :190-196), written to
+   * norm_out[((norm_frame_offset + t) * H + h) * W + w][norm_ld]; `out` may then be NULL (raw result not needed). */
+  void* norm_out;
+  const void* norm_gamma; /* [Cout] */
+  int32_t norm_ld, norm_frame_offset;
 } sf_conv_args;
 
 enum sf_conv_structure { SF_CONV_AUTO = 0, SF_CONV_IGEMM = 1 /* A tile gathered per tap (every shape) */,

@@ -87,6 +87,7 @@ class ConvArgs(C.Structure):
         [(n, C.c_void_p) for n in ("x", "w", "bias", "out", "resid", "out_f32")]
         + [(n, C.c_int32) for n in ("Tout", "H", "W", "Hin", "Win", "Cin", "Cout", "kt", "kh", "kw", "upsample",
                                     "t_in_offset", "ldw", "ldo", "ldr", "out_frame_offset", "interleave_c", "epilogue", "structure")]
+        + [("norm_out", C.c_void_p), ("norm_gamma", C.c_void_p), ("norm_ld", C.c_int32), ("norm_frame_offset", C.c_int32)]
     )
 
 

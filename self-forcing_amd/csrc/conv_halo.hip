@@ -36,6 +36,9 @@ struct HaloP {
   const bf16_t* bias;
   bf16_t* out;
   const bf16_t* resid;
+  bf16_t* norm_out;          // optional second output: SiLU(RMS_norm(y)) for the next convolution (tiles_n == 1 only)
+  const bf16_t* norm_gamma;
+  int norm_ld, norm_frame0;
   int H, W, Hin, Win, up, Cin, Cout, cpt, kt, t_off, ldw, ldo, ldr, out_frame0;
   int patches_h, patches_w, tiles_n;
   unsigned x_bytes;
@@ -284,6 +287,23 @@ __global__ __launch_bounds__(HALO_THREADS) void conv_halo_kernel(HaloP p) {
   }
   __syncthreads();
   constexpr int CPR = 4 * NT;                // 16-byte chunks per position
+  // Optional fused RMS_norm + SiLU (vae.py:41-56, :190-196) of the tile for the NEXT convolution's input volume: with all
+  // output channels in this tile a position's row is complete in LDS.  Same arithmetic as sf_rmsnorm_silu_cl on the
+  // bf16-rounded values: x * sqrt(C) / max(||x||, 1e-12) * gamma, SiLU, one rounding.
+  float* rinv = reinterpret_cast<float*>(smem + 256 * RBP);
+  if (p.norm_out) {
+    const int row = tid >> 1, half = tid & 1;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPR / 2; ++i) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(obuf + row * RBP + (half * (CPR / 2) + i) * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+    }
+    ss += __shfl_xor(ss, 1, 64);
+    if (half == 0) rinv[row] = sqrtf((float)BN) / fmaxf(sqrtf(ss), 1e-12f);
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < (256 * CPR) / HALO_THREADS; ++i) {
     const int id = i * HALO_THREADS + tid;
@@ -291,7 +311,15 @@ __global__ __launch_bounds__(HALO_THREADS) void conv_halo_kernel(HaloP p) {
     const int h = h0 + (row >> 4), w = w0 + (row & 15), n = n0 + ch * 8;
     if (h < p.H && w < p.W && n < p.Cout) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(obuf + row * RBP + ch * 16);
-      *reinterpret_cast<bf16x8*>(p.out + ((frame_row + h) * p.W + w) * p.ldo + n) = v;
+      if (p.out) *reinterpret_cast<bf16x8*>(p.out + ((frame_row + h) * p.W + w) * p.ldo + n) = v;
+      if (p.norm_out) {
+        const float inv = rinv[row];
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(p.norm_gamma + n);
+        bf16x8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (bf16_t)silu_f((float)v[j] * inv * (float)g[j]);
+        *reinterpret_cast<bf16x8*>(p.norm_out + (((long)(p.norm_frame0 + t) * p.H + h) * p.W + w) * p.norm_ld + n) = o8;
+      }
     }
   }
 }
@@ -300,6 +328,7 @@ template <int NT, int TPC>
 int launch_halo(const HaloP& p, int tiles, int epi, hipStream_t s) {
   constexpr int LDS = PLANE_RING * PLANE_SLOT + 3 * TPC * 32 * NT * 64 + 8 * 1024;
   static_assert(LDS <= 160 * 1024, "LDS budget");
+  static_assert(256 * (64 * NT + 16) + 1024 <= LDS, "epilogue staging + norm factors fit the k-loop's LDS");
   static bool done = false;   // one-time registration of the kernels' LDS size (idempotent)
   if (!done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT, TPC, SF_CONV_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -315,19 +344,22 @@ int launch_halo(const HaloP& p, int tiles, int epi, hipStream_t s) {
 
 }  // namespace
 
-// Returns 1 when the problem is outside this kernel's domain (the caller then uses conv_igemm), 0 after a launch,
-// negative on error.  Domain: 3 x 3 spatial taps (kt 1 or 3), Cin % 32 == 0, Cout a multiple of 96 or of 192, bf16
+// Returns 1 when the problem is outside this kernel's domain (the caller then uses conv_igemm; with a fused norm
+// output that is an error the caller reports), 0 after a launch, negative on error.  Domain: 3 x 3 spatial taps (kt 1 or 3), Cin % 32 == 0, Cout a multiple of 96 or of 192, bf16
 // output with bias / bias + residual, no channel -> frame interleave.
 __attribute__((visibility("hidden"))) int sf_conv_halo_launch(const sf_conv_args* a, void* stream) {
   if (!(a->kh == 3 && a->kw == 3) || a->interleave_c != 0 || a->Cin % 32 != 0) return 1;
   if (a->epilogue != SF_CONV_BIAS && a->epilogue != SF_CONV_BIAS_RESID) return 1;
-  if ((a->Cout & 7) != 0 || (a->ldo & 7) != 0) return 1;
+  if ((a->Cout & 7) != 0 || (a->out && (a->ldo & 7) != 0)) return 1;
+  if (a->norm_out && !((a->Cout == 96 || a->Cout == 192) && a->norm_gamma && a->norm_ld >= a->Cout && (a->norm_ld & 7) == 0)) return 1;
+  if (!a->out && !a->norm_out) return 1;
   const int nt = a->Cout % 192 == 0 ? 6 : a->Cout % 96 == 0 ? 3 : 0;
   if (nt == 0) return 1;
   if (a->H < 16 || a->W < 16) return 1;
   HaloP p;
   p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = (const bf16_t*)a->bias;
   p.out = (bf16_t*)a->out; p.resid = (const bf16_t*)a->resid;
+  p.norm_out = (bf16_t*)a->norm_out; p.norm_gamma = (const bf16_t*)a->norm_gamma; p.norm_ld = a->norm_ld; p.norm_frame0 = a->norm_frame_offset;
   p.H = a->H; p.W = a->W; p.Hin = a->Hin; p.Win = a->Win; p.up = a->upsample;
   p.Cin = a->Cin; p.Cout = a->Cout; p.cpt = a->Cin / 32; p.kt = a->kt; p.t_off = a->t_in_offset;
   p.ldw = a->ldw; p.ldo = a->ldo; p.ldr = a->ldr; p.out_frame0 = a->out_frame_offset;

@@ -399,6 +399,7 @@ extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
   SF_CHECK(a != nullptr, "sf_conv_igemm: null args");
   SF_CHECK(a->structure >= SF_CONV_AUTO && a->structure <= SF_CONV_HALO, "sf_conv_igemm: unknown structure %d", a->structure);
   SF_CHECK(a->x && a->w && a->bias, "sf_conv_igemm: null tensor");
+  SF_CHECK(!a->norm_out || a->structure != SF_CONV_IGEMM, "sf_conv_igemm: the fused norm output exists in the halo kernel only");
   SF_CHECK(a->Tout > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0, "sf_conv_igemm: empty problem");
   SF_CHECK(a->Cin % 32 == 0, "sf_conv_igemm: Cin=%d must be a multiple of 32 (pad the channels)", a->Cin);
   SF_CHECK((a->kh == 3 && a->kw == 3) || (a->kh == 1 && a->kw == 1), "sf_conv_igemm: spatial taps must be 3x3 or 1x1");
@@ -416,10 +417,11 @@ extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
   if (a->epilogue == SF_CONV_BIAS_CLAMP_F32) {
     SF_CHECK(a->out_f32 != nullptr && a->interleave_c == 0, "sf_conv_igemm: float epilogue needs out_f32 and no interleave");
   } else {
-    SF_CHECK(a->out != nullptr && a->ldo % 4 == 0 && a->Cout % 4 == 0, "sf_conv_igemm: bf16 output needs out, ldo %% 4 == 0, Cout %% 4 == 0");
-    SF_CHECK((uintptr_t)a->out % 8 == 0, "sf_conv_igemm: misaligned output");
+    SF_CHECK((a->out != nullptr || a->norm_out != nullptr) && a->Cout % 4 == 0, "sf_conv_igemm: bf16 output needs out (or norm_out) and Cout %% 4 == 0");
+    SF_CHECK(!a->out || (a->ldo % 4 == 0 && (uintptr_t)a->out % 8 == 0), "sf_conv_igemm: misaligned output / ldo %% 4 != 0");
+    SF_CHECK(!a->norm_out || ((uintptr_t)a->norm_out % 16 == 0 && (uintptr_t)a->norm_gamma % 16 == 0), "sf_conv_igemm: misaligned norm output");
     SF_CHECK(a->interleave_c == 0 || (a->interleave_c * 2 == a->Cout && a->interleave_c % 4 == 0), "sf_conv_igemm: interleave_c must be Cout/2");
-    SF_CHECK(a->ldo >= (a->interleave_c ? a->interleave_c : a->Cout), "sf_conv_igemm: ldo too small");
+    SF_CHECK(!a->out || a->ldo >= (a->interleave_c ? a->interleave_c : a->Cout), "sf_conv_igemm: ldo too small");
     if (a->epilogue == SF_CONV_BIAS_RESID)
       SF_CHECK(a->resid != nullptr && a->ldr % 4 == 0 && a->ldr >= a->Cout && a->interleave_c == 0, "sf_conv_igemm: residual epilogue needs resid/ldr");
   }
@@ -428,8 +430,8 @@ extern "C" int sf_conv_igemm(const sf_conv_args* a, void* stream) {
     // (channel slice, frame) instead of once per tap), conv_halo.hip
     const int rc = sf_conv_halo_launch(a, stream);
     SF_CHECK(rc >= 0, "sf_conv_igemm: halo kernel failed");
-    SF_CHECK(rc == 0 || a->structure == SF_CONV_AUTO, "sf_conv_igemm: the halo structure needs 3x3 spatial taps, Cout %% 96 == 0, H, W >= 16, "
-             "a bf16 bias / bias + residual epilogue and no interleave");
+    SF_CHECK(rc == 0 || (a->structure == SF_CONV_AUTO && !a->norm_out), "sf_conv_igemm: the halo structure needs 3x3 spatial taps, "
+             "Cout %% 96 == 0 (a fused norm output: Cout 96 or 192), H, W >= 16, a bf16 bias / bias + residual epilogue and no interleave");
     if (rc == 0) {
       SF_HIP_LAUNCH_CHECK("sf_conv_igemm");
       return 0;

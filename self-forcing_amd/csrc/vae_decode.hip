@@ -128,10 +128,17 @@ int check_model(const sf_vae_model* m, int h, int w) {
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// RMS_norm + SiLU of a convolution's output can ride in its epilogue (second output of the halo kernel) when the
+// convolution is 3 x 3 spatial with 96 or 192 output channels at a resolution the halo kernel takes
+struct NormOut { void* dst; const void* gamma; int ld; };   // dst: base of the consumer's input volume (frames at offset 2)
+
+bool can_fuse_norm(const sf_vae_conv& c, int H, int W) { return c.kh == 3 && c.kw == 3 && (c.cout == 96 || c.cout == 192) && H >= 16 && W >= 16; }
+
 int conv(const sf_vae_conv& c, const void* x, int Tout, int H, int W, int upsample, int t_off, void* out, int ldo, int out_frame0,
-         int interleave_c, int epi, const void* resid, int ldr, float* out_f32, void* stream) {
+         int interleave_c, int epi, const void* resid, int ldr, float* out_f32, void* stream, const NormOut* norm = nullptr) {
   sf_conv_args a;
   memset(&a, 0, sizeof(a));
+  if (norm) { a.norm_out = norm->dst; a.norm_gamma = norm->gamma; a.norm_ld = norm->ld; a.norm_frame_offset = 2; }
   a.x = x; a.w = c.w; a.bias = c.bias; a.out = out; a.resid = resid; a.out_f32 = out_f32;
   a.Tout = Tout; a.H = H; a.W = W; a.Hin = upsample ? H / 2 : H; a.Win = upsample ? W / 2 : W;
   a.Cin = c.cin; a.Cout = c.cout; a.kt = c.kt; a.kh = c.kh; a.kw = c.kw; a.upsample = upsample; a.t_in_offset = t_off;
@@ -157,22 +164,33 @@ int shift_history(char* buf, int T, size_t frame_bytes, hipStream_t s) {
   return 0;
 }
 
-// ResidualBlock.forward (vae.py:202-221) on T frames of H x W
-int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, int T, int H, int W, void* stream) {
+// ResidualBlock.forward (vae.py:202-221) on T frames of H x W.  `in_normed`: the producer of x_in already wrote
+// SiLU(RMS_norm(x_in)) into conv1's input volume (fused epilogue); `next`: where (and with which gamma) this block's
+// output should ALSO be written normalised -- the next block's conv1 input or the head's --, if its conv2 can do that.
+// Returns through *out_normed whether it did.
+int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, int T, int H, int W, void* stream,
+             bool in_normed = false, const NormOut* next = nullptr, bool* out_normed = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)T * H * W;
   const int cin = r.conv1.cin, cout = r.conv1.cout;
   const size_t f1 = vol(1, H, W, cin), f2 = vol(1, H, W, cout);
-  SF_TRY(sf_rmsnorm_silu_cl(x_in, r.gamma1, b.a1 + 2 * f1, rows, cin, 1, stream));
-  SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, 0, p.y1, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+  if (!in_normed) SF_TRY(sf_rmsnorm_silu_cl(x_in, r.gamma1, b.a1 + 2 * f1, rows, cin, 1, stream));
+  if (can_fuse_norm(r.conv1, H, W)) {   // conv1's raw output is only ever read by the norm in front of conv2
+    const NormOut n2 = {b.a2, r.gamma2, cout};
+    SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, 0, nullptr, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream, &n2));
+  } else {
+    SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, 0, p.y1, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+    SF_TRY(sf_rmsnorm_silu_cl(p.y1, r.gamma2, b.a2 + 2 * f2, rows, cout, 1, stream));
+  }
   SF_TRY(shift_history(b.a1, T, f1, s));
-  SF_TRY(sf_rmsnorm_silu_cl(p.y1, r.gamma2, b.a2 + 2 * f2, rows, cout, 1, stream));
   const char* resid = x_in;
   if (r.shortcut.w) {
     SF_TRY(conv(r.shortcut, x_in, T, H, W, 0, 0, p.sc, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
     resid = p.sc;
   }
-  SF_TRY(conv(r.conv2, b.a2, T, H, W, 0, 0, out, cout, 0, 0, SF_CONV_BIAS_RESID, resid, cout, nullptr, stream));
+  const bool fuse_next = next && next->ld == r.conv2.cout && can_fuse_norm(r.conv2, H, W);
+  SF_TRY(conv(r.conv2, b.a2, T, H, W, 0, 0, out, cout, 0, 0, SF_CONV_BIAS_RESID, resid, cout, nullptr, stream, fuse_next ? next : nullptr));
+  if (out_normed) *out_normed = fuse_next;
   SF_TRY(shift_history(b.a2, T, f2, s));
   return 0;
 }
@@ -239,9 +257,12 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
   SF_TRY(attention_block(m, p, p.x[0], h * w, C0, stream));
   SF_TRY(resblock(m->mid2, p.mid2, p, p.x[0], p.x[0], 1, h, w, stream));
 
-  // upsample stages (vae.py:448-452)
+  // upsample stages (vae.py:448-452).  `normed`: the next consumer's input volume already holds SiLU(RMS_norm(cur))
   int T = 1;
   const char* cur = p.x[0];   // the stage's running activation
+  bool normed = false;
+  const int L = m->n_stages - 1;
+  const int Ch = m->head_conv.cin;
   for (int i = 0; i < m->n_stages; ++i) {
     const int H = p.H[i], W = p.W[i];
     const bool has_up = i + 1 < m->n_stages;
@@ -250,7 +271,17 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
       const sf_vae_resblock& r = res_at(m, i, j);
       char* out = p.x[i];
       if (j == m->res_per_stage - 1 && has_tc) out = p.tc[i] + 2 * vol(1, H, W, m->time_conv[i].cin);   // feeds the time conv
-      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, T, H, W, stream));
+      // who reads this block's output through a norm: the next block of the stage, or (last block of the last stage) the head
+      NormOut next = {nullptr, nullptr, 0};
+      if (j + 1 < m->res_per_stage) {
+        const sf_vae_resblock& rn = res_at(m, i, j + 1);
+        next = {p.blk[i * m->res_per_stage + j + 1].a1, rn.gamma1, rn.conv1.cin};
+      } else if (!has_up) {
+        next = {p.head_in, m->head_gamma, Ch};
+      }
+      bool out_normed = false;
+      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, T, H, W, stream, normed, next.dst ? &next : nullptr, &out_normed));
+      normed = out_normed;
       cur = out;
     }
     if (!has_up) break;
@@ -266,16 +297,20 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
       up_in = p.ty[i];
       Tn = 2 * T;
     }
-    // nearest 2x + Conv2d 3x3 per frame (vae.py:139-141), fused
-    SF_TRY(conv(uc, up_in, Tn, 2 * H, 2 * W, 1, 0, p.xi[i + 1], uc.cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+    // nearest 2x + Conv2d 3x3 per frame (vae.py:139-141), fused; its output feeds the next stage's first block, whose
+    // norm1 rides in this convolution's epilogue when the halo kernel takes it
+    const sf_vae_resblock& rn = res_at(m, i + 1, 0);
+    const NormOut nn = {p.blk[(i + 1) * m->res_per_stage].a1, rn.gamma1, rn.conv1.cin};
+    const bool fuse = rn.conv1.cin == uc.cout && can_fuse_norm(uc, 2 * H, 2 * W);
+    SF_TRY(conv(uc, up_in, Tn, 2 * H, 2 * W, 1, 0, p.xi[i + 1], uc.cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream, fuse ? &nn : nullptr));
+    normed = fuse;
     cur = p.xi[i + 1];
     T = Tn;
   }
 
   // head (vae.py:455-471): RMS-norm, SiLU, causal conv to 3 channels; float, clamp
-  const int L = m->n_stages - 1;
-  const int Ch = m->head_conv.cin;
-  SF_TRY(sf_rmsnorm_silu_cl(cur, m->head_gamma, p.head_in + 2 * vol(1, p.H[L], p.W[L], Ch), (long)T * p.H[L] * p.W[L], Ch, 1, stream));
+  if (!normed)
+    SF_TRY(sf_rmsnorm_silu_cl(cur, m->head_gamma, p.head_in + 2 * vol(1, p.H[L], p.W[L], Ch), (long)T * p.H[L] * p.W[L], Ch, 1, stream));
   SF_TRY(conv(m->head_conv, p.head_in, T, p.H[L], p.W[L], 0, 0, nullptr, 0, 0, 0, SF_CONV_BIAS_CLAMP_F32, nullptr, 0, pixels_out, stream));
   SF_TRY(shift_history(p.head_in, T, vol(1, p.H[L], p.W[L], Ch), s));
   return 0;
