@@ -344,18 +344,21 @@ typedef struct sf_vae_model {             /* Decoder3d + conv2, vae.py:369-421, 
   sf_vae_conv head_conv;                  /* decoder.head.2 (cout = 3) */
 } sf_vae_model;
 
-/* Per-stream persistent state = the input volumes (2 history frames + new frames) of every cached
- * convolution; scratch = everything else, reusable by any stream that does not overlap in time. */
+/* Per-stream persistent state = the input volumes of every cached convolution (2 history frames + new frames, as a
+ * window that slides through 2 + 4 T frames); scratch = everything else, reusable by any stream that does not overlap
+ * in time. */
 size_t sf_vae_state_bytes(const sf_vae_model* model, int lat_h, int lat_w);
 size_t sf_vae_scratch_bytes(const sf_vae_model* model, int lat_h, int lat_w);
 /* WanVAE_.clear_cache (vae.py:610-617): zero every history. */
 int sf_vae_reset(const sf_vae_model* model, void* state, size_t state_bytes, int lat_h, int lat_w, void* stream);
 /* One iteration of the per-latent-frame loop of decode / cached_decode (vae.py:566-578):
- * latent_frame [z][lat_h][lat_w] bf16 -> pixels [T][3][8 lat_h][8 lat_w] float32 in [-1, 1], T = 1 when
- * `first_chunk` (the frame that follows a reset), else 4 (vae.py:109-111, :134-137). */
+ * latent_frame [z][lat_h][lat_w] bf16 -> pixels [T][3][8 lat_h][8 lat_w] float32 in [-1, 1], T = 1 for
+ * frame_index 0 (the frame that follows a reset), else 4 (vae.py:109-111, :134-137).  `frame_index` = the number of
+ * latent frames decoded into `state` since its reset: it positions the history windows (the library keeps no state of
+ * its own), so it must count up by one per call. */
 int sf_vae_decode_frame(const sf_vae_model* model, void* state, size_t state_bytes, void* scratch,
                         size_t scratch_bytes, const void* latent_frame, int lat_h, int lat_w,
-                        int first_chunk, float* pixels_out, void* stream);
+                        int frame_index, float* pixels_out, void* stream);
 
 /* ==========================================================================================
  * umT5 text encoder (prompt token ids -> prompt embeddings): WanTextEncoder.forward after its tokenizer

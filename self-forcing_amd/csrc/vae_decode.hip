@@ -4,11 +4,14 @@
 //
 // Host-side only (no kernels here).  The reference threads a list of 32 cache tensors and an index
 // counter through the modules and re-concatenates [cache, x] in front of every convolution; here each
-// cached convolution owns ONE input volume [2 + T][H][W][C] in the per-stream state: its producer (the
-// RMS-norm/SiLU kernel, or the previous block's epilogue) writes the T new frames behind the two
-// history frames, the convolution gathers its temporal taps from frames t, t+1, t+2, and the last two
-// frames are then copied to the front (the cache update of vae.py:206-216; for T = 1 that is the
-// "borrow the last frame of the previous cache" branch).  A zeroed history IS the reference's zero
+// cached convolution owns ONE input volume in the per-stream state: its producer (the RMS-norm/SiLU kernel, or the
+// previous convolution's epilogue) writes the T new frames behind the two history frames, the convolution gathers its
+// temporal taps from frames t, t+1, t+2, and the last two frames become the next call's history (the cache update of
+// vae.py:206-216; for T = 1 that is the "borrow the last frame of the previous cache" branch).  The volume holds
+// 2 + 4 T frames and the window [history | new frames] SLIDES through it: the next call's history is where this
+// call's last two frames already are, and only every fourth call copies two frames back to the front (round 1
+// copied them after every convolution: 2756 copies and 5 % of a clip's decode time).  The window's position is a pure
+// function of the number of frames decoded since the reset, which the caller passes (no host state here).  A zeroed history IS the reference's zero
 // padding of the first chunk, so there is no first-chunk special case in the convolutions.  The two
 // quirks of Resample's bookkeeping (vae.py:104-132) are kept: the first chunk after a reset skips the
 // time convolution (one output frame), and its features never enter that convolution's history.
@@ -52,6 +55,23 @@ struct Plan {
 
 inline size_t vol(int T, int H, int W, int C) { return (size_t)T * H * W * C * 2; }
 
+// Sliding history window of a cached convolution's input volume (capacity 2 + HIST_K * Tmax frames).  Call n (0-based,
+// counted from the reset) brings T_n = 1 (n == 0: the first chunk has one frame at every stage) or Tmax new frames.
+constexpr int HIST_K = 4;
+inline int hist_frames(int Tmax) { return 2 + HIST_K * Tmax; }
+inline int hist_cursor(int n, int Tmax, int T0 = 1) {   // first history frame of the volume's call n (its first call brings T0 frames)
+  int c = 0;
+  for (int k = 0; k < n; ++k) {
+    c += k == 0 ? T0 : Tmax;
+    if (c + 2 + Tmax > hist_frames(Tmax)) c = 0;  // the window of call k + 1 would not fit: it starts at the front again
+  }
+  return c;
+}
+inline bool hist_wraps(int n, int Tmax, int T0 = 1) {    // does the window of call n + 1 start at the front again?
+  const int c = hist_cursor(n, Tmax, T0) + (n == 0 ? T0 : Tmax);
+  return c + 2 + Tmax > hist_frames(Tmax);
+}
+
 const sf_vae_resblock& res_at(const sf_vae_model* m, int stage, int j) { return m->res_host[stage * m->res_per_stage + j]; }
 
 Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w) {
@@ -67,21 +87,21 @@ Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w) 
     if (i + 1 < m->n_stages && m->temporal_up[i]) T *= 2;
   }
   Carve st(state);
-  p.c1_in = st.take(vol(3, h, w, m->conv1.cin));
+  p.c1_in = st.take(vol(hist_frames(1), h, w, m->conv1.cin));
   const int C0 = m->conv1.cout;
-  p.mid0.a1 = st.take(vol(3, h, w, C0)); p.mid0.a2 = st.take(vol(3, h, w, C0));
-  p.mid2.a1 = st.take(vol(3, h, w, C0)); p.mid2.a2 = st.take(vol(3, h, w, C0));
+  p.mid0.a1 = st.take(vol(hist_frames(1), h, w, C0)); p.mid0.a2 = st.take(vol(hist_frames(1), h, w, C0));
+  p.mid2.a1 = st.take(vol(hist_frames(1), h, w, C0)); p.mid2.a2 = st.take(vol(hist_frames(1), h, w, C0));
   for (int i = 0; i < m->n_stages; ++i) {
     for (int j = 0; j < m->res_per_stage; ++j) {
       const sf_vae_resblock& r = res_at(m, i, j);
       BlockBufs& b = p.blk[i * m->res_per_stage + j];
-      b.a1 = st.take(vol(2 + p.Tmax[i], p.H[i], p.W[i], r.conv1.cin));
-      b.a2 = st.take(vol(2 + p.Tmax[i], p.H[i], p.W[i], r.conv2.cin));
+      b.a1 = st.take(vol(hist_frames(p.Tmax[i]), p.H[i], p.W[i], r.conv1.cin));
+      b.a2 = st.take(vol(hist_frames(p.Tmax[i]), p.H[i], p.W[i], r.conv2.cin));
     }
-    p.tc[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? st.take(vol(2 + p.Tmax[i], p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
+    p.tc[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? st.take(vol(hist_frames(p.Tmax[i]), p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
   }
   const int L = m->n_stages - 1;
-  p.head_in = st.take(vol(2 + p.Tmax[L], p.H[L], p.W[L], m->head_conv.cin));
+  p.head_in = st.take(vol(hist_frames(p.Tmax[L]), p.H[L], p.W[L], m->head_conv.cin));
   p.state_total = st.off;
 
   Carve sc(scratch);
@@ -130,7 +150,7 @@ int check_model(const sf_vae_model* m, int h, int w) {
 
 // RMS_norm + SiLU of a convolution's output can ride in its epilogue (second output of the halo kernel) when the
 // convolution is 3 x 3 spatial with 96 or 192 output channels at a resolution the halo kernel takes
-struct NormOut { void* dst; const void* gamma; int ld; };   // dst: base of the consumer's input volume (frames at offset 2)
+struct NormOut { void* dst; const void* gamma; int ld; int frame_off; };   // dst: base of the consumer's input volume; its new frames start at frame_off
 
 bool can_fuse_norm(const sf_vae_conv& c, int H, int W) { return c.kh == 3 && c.kw == 3 && (c.cout == 96 || c.cout == 192) && H >= 16 && W >= 16; }
 
@@ -138,7 +158,7 @@ int conv(const sf_vae_conv& c, const void* x, int Tout, int H, int W, int upsamp
          int interleave_c, int epi, const void* resid, int ldr, float* out_f32, void* stream, const NormOut* norm = nullptr) {
   sf_conv_args a;
   memset(&a, 0, sizeof(a));
-  if (norm) { a.norm_out = norm->dst; a.norm_gamma = norm->gamma; a.norm_ld = norm->ld; a.norm_frame_offset = 2; }
+  if (norm) { a.norm_out = norm->dst; a.norm_gamma = norm->gamma; a.norm_ld = norm->ld; a.norm_frame_offset = norm->frame_off; }
   a.x = x; a.w = c.w; a.bias = c.bias; a.out = out; a.resid = resid; a.out_f32 = out_f32;
   a.Tout = Tout; a.H = H; a.W = W; a.Hin = upsample ? H / 2 : H; a.Win = upsample ? W / 2 : W;
   a.Cin = c.cin; a.Cout = c.cout; a.kt = c.kt; a.kh = c.kh; a.kw = c.kw; a.upsample = upsample; a.t_in_offset = t_off;
@@ -155,12 +175,13 @@ int gemm(const void* a, int lda, const void* w, int ldw, const void* bias, void*
   return sf_gemm_bf16(&g, stream);
 }
 
-// the cache update: the last two of the 2 + T frames move to the front
-int shift_history(char* buf, int T, size_t frame_bytes, hipStream_t s) {
-  for (int k = 0; k < 2; ++k) {
-    hipError_t e = hipMemcpyAsync(buf + k * frame_bytes, buf + (size_t)(T + k) * frame_bytes, frame_bytes, hipMemcpyDeviceToDevice, s);
-    SF_CHECK(e == hipSuccess, "sf_vae: history copy failed: %s", hipGetErrorString(e));
-  }
+// the cache update after call n: the window slides by the call's T frames; only when the next window would not fit are
+// the last two frames copied to the front
+int shift_history(char* buf, int n, int T, int Tmax, size_t frame_bytes, hipStream_t s, int T0 = 1) {
+  if (!hist_wraps(n, Tmax, T0)) return 0;
+  const int c = hist_cursor(n, Tmax, T0);
+  hipError_t e = hipMemcpyAsync(buf, buf + (size_t)(c + T) * frame_bytes, 2 * frame_bytes, hipMemcpyDeviceToDevice, s);
+  SF_CHECK(e == hipSuccess, "sf_vae: history copy failed: %s", hipGetErrorString(e));
   return 0;
 }
 
@@ -168,30 +189,31 @@ int shift_history(char* buf, int T, size_t frame_bytes, hipStream_t s) {
 // SiLU(RMS_norm(x_in)) into conv1's input volume (fused epilogue); `next`: where (and with which gamma) this block's
 // output should ALSO be written normalised -- the next block's conv1 input or the head's --, if its conv2 can do that.
 // Returns through *out_normed whether it did.
-int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, int T, int H, int W, void* stream,
-             bool in_normed = false, const NormOut* next = nullptr, bool* out_normed = nullptr) {
+int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, int n, int T, int Tmax, int H, int W,
+             void* stream, bool in_normed = false, const NormOut* next = nullptr, bool* out_normed = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   const long rows = (long)T * H * W;
   const int cin = r.conv1.cin, cout = r.conv1.cout;
   const size_t f1 = vol(1, H, W, cin), f2 = vol(1, H, W, cout);
-  if (!in_normed) SF_TRY(sf_rmsnorm_silu_cl(x_in, r.gamma1, b.a1 + 2 * f1, rows, cin, 1, stream));
+  const int c = hist_cursor(n, Tmax);                 // both volumes of the block slide alike
+  if (!in_normed) SF_TRY(sf_rmsnorm_silu_cl(x_in, r.gamma1, b.a1 + (size_t)(c + 2) * f1, rows, cin, 1, stream));
   if (can_fuse_norm(r.conv1, H, W)) {   // conv1's raw output is only ever read by the norm in front of conv2
-    const NormOut n2 = {b.a2, r.gamma2, cout};
-    SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, 0, nullptr, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream, &n2));
+    const NormOut n2 = {b.a2, r.gamma2, cout, c + 2};
+    SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, c, nullptr, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream, &n2));
   } else {
-    SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, 0, p.y1, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
-    SF_TRY(sf_rmsnorm_silu_cl(p.y1, r.gamma2, b.a2 + 2 * f2, rows, cout, 1, stream));
+    SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, c, p.y1, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+    SF_TRY(sf_rmsnorm_silu_cl(p.y1, r.gamma2, b.a2 + (size_t)(c + 2) * f2, rows, cout, 1, stream));
   }
-  SF_TRY(shift_history(b.a1, T, f1, s));
+  SF_TRY(shift_history(b.a1, n, T, Tmax, f1, s));
   const char* resid = x_in;
   if (r.shortcut.w) {
     SF_TRY(conv(r.shortcut, x_in, T, H, W, 0, 0, p.sc, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
     resid = p.sc;
   }
   const bool fuse_next = next && next->ld == r.conv2.cout && can_fuse_norm(r.conv2, H, W);
-  SF_TRY(conv(r.conv2, b.a2, T, H, W, 0, 0, out, cout, 0, 0, SF_CONV_BIAS_RESID, resid, cout, nullptr, stream, fuse_next ? next : nullptr));
+  SF_TRY(conv(r.conv2, b.a2, T, H, W, 0, c, out, cout, 0, 0, SF_CONV_BIAS_RESID, resid, cout, nullptr, stream, fuse_next ? next : nullptr));
   if (out_normed) *out_normed = fuse_next;
-  SF_TRY(shift_history(b.a2, T, f2, s));
+  SF_TRY(shift_history(b.a2, n, T, Tmax, f2, s));
   return 0;
 }
 
@@ -235,9 +257,12 @@ extern "C" int sf_vae_reset(const sf_vae_model* m, void* state, size_t state_byt
 }
 
 extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
-                                   const void* latent_frame, int h, int w, int first_chunk, float* pixels_out, void* stream) {
+                                   const void* latent_frame, int h, int w, int frame_index, float* pixels_out, void* stream) {
   SF_TRY(check_model(m, h, w));
   SF_CHECK(latent_frame && pixels_out, "sf_vae_decode_frame: null tensor");
+  SF_CHECK(frame_index >= 0 && frame_index < (1 << 20), "sf_vae_decode_frame: frame_index %d (latent frames decoded since the reset)", frame_index);
+  const int n = frame_index;
+  const bool first_chunk = n == 0;
   const Plan p = make_plan(m, state, scratch, h, w);
   SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_decode_frame: state too small (%zu < %zu)", state_bytes, p.state_total);
   SF_CHECK(scratch && scratch_bytes >= p.scratch_total, "sf_vae_decode_frame: scratch too small (%zu < %zu)", scratch_bytes, p.scratch_total);
@@ -246,16 +271,17 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
 
   // un-scale + conv2 (1x1x1) -> the new frame of decoder.conv1's input volume; conv1 (vae.py:425-438)
   const size_t f_in = vol(1, h, w, m->conv1.cin);
-  SF_TRY(sf_vae_prepare_latent(latent_frame, m->latent_mean, m->latent_std, m->conv2_w, m->conv2_b, p.c1_in + 2 * f_in, m->z_dim, h, w,
+  const int c1 = hist_cursor(n, 1);
+  SF_TRY(sf_vae_prepare_latent(latent_frame, m->latent_mean, m->latent_std, m->conv2_w, m->conv2_b, p.c1_in + (size_t)(c1 + 2) * f_in, m->z_dim, h, w,
                                m->conv1.cin, stream));
-  SF_TRY(conv(m->conv1, p.c1_in, 1, h, w, 0, 0, p.xi[0], C0, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
-  SF_TRY(shift_history(p.c1_in, 1, f_in, s));
+  SF_TRY(conv(m->conv1, p.c1_in, 1, h, w, 0, c1, p.xi[0], C0, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+  SF_TRY(shift_history(p.c1_in, n, 1, 1, f_in, s));
 
   // middle (vae.py:441-445): res, attention, res -- all on the one latent-rate frame
   SF_CHECK(res_at(m, 0, 0).conv1.cin == C0 && res_at(m, 0, 0).conv1.cout == C0, "sf_vae_decode_frame: stage 0 must keep the decoder width");
-  SF_TRY(resblock(m->mid0, p.mid0, p, p.xi[0], p.x[0], 1, h, w, stream));
+  SF_TRY(resblock(m->mid0, p.mid0, p, p.xi[0], p.x[0], n, 1, 1, h, w, stream));
   SF_TRY(attention_block(m, p, p.x[0], h * w, C0, stream));
-  SF_TRY(resblock(m->mid2, p.mid2, p, p.x[0], p.x[0], 1, h, w, stream));
+  SF_TRY(resblock(m->mid2, p.mid2, p, p.x[0], p.x[0], n, 1, 1, h, w, stream));
 
   // upsample stages (vae.py:448-452).  `normed`: the next consumer's input volume already holds SiLU(RMS_norm(cur))
   int T = 1;
@@ -264,23 +290,27 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
   const int L = m->n_stages - 1;
   const int Ch = m->head_conv.cin;
   for (int i = 0; i < m->n_stages; ++i) {
-    const int H = p.H[i], W = p.W[i];
+    const int H = p.H[i], W = p.W[i], Tmax = p.Tmax[i];
     const bool has_up = i + 1 < m->n_stages;
     const bool has_tc = has_up && m->time_conv[i].w != nullptr;
+    SF_CHECK(T == (first_chunk ? 1 : Tmax), "sf_vae_decode_frame: stage %d expects %d frames, has %d", i, first_chunk ? 1 : Tmax, T);
+    // the time convolution's volume only counts the calls in which it runs (not the first chunk, whose features never enter
+    // its history: the quirk of vae.py:104-132); all of them bring Tmax frames
+    const int n_tc = n - 1, c_tc = first_chunk ? 0 : hist_cursor(n_tc, Tmax, Tmax);
     for (int j = 0; j < m->res_per_stage; ++j) {
       const sf_vae_resblock& r = res_at(m, i, j);
       char* out = p.x[i];
-      if (j == m->res_per_stage - 1 && has_tc) out = p.tc[i] + 2 * vol(1, H, W, m->time_conv[i].cin);   // feeds the time conv
+      if (j == m->res_per_stage - 1 && has_tc) out = p.tc[i] + (size_t)(c_tc + 2) * vol(1, H, W, m->time_conv[i].cin);   // feeds the time conv
       // who reads this block's output through a norm: the next block of the stage, or (last block of the last stage) the head
-      NormOut next = {nullptr, nullptr, 0};
+      NormOut next = {nullptr, nullptr, 0, 0};
       if (j + 1 < m->res_per_stage) {
         const sf_vae_resblock& rn = res_at(m, i, j + 1);
-        next = {p.blk[i * m->res_per_stage + j + 1].a1, rn.gamma1, rn.conv1.cin};
+        next = {p.blk[i * m->res_per_stage + j + 1].a1, rn.gamma1, rn.conv1.cin, hist_cursor(n, Tmax) + 2};
       } else if (!has_up) {
-        next = {p.head_in, m->head_gamma, Ch};
+        next = {p.head_in, m->head_gamma, Ch, hist_cursor(n, Tmax) + 2};
       }
       bool out_normed = false;
-      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, T, H, W, stream, normed, next.dst ? &next : nullptr, &out_normed));
+      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, n, T, Tmax, H, W, stream, normed, next.dst ? &next : nullptr, &out_normed));
       normed = out_normed;
       cur = out;
     }
@@ -292,15 +322,15 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
       // Resample 'upsample3d' (vae.py:112-137): (3,1,1) causal conv C -> 2C, channel halves -> frames 2t, 2t+1
       const sf_vae_conv& tcv = m->time_conv[i];
       SF_CHECK(tcv.cout == 2 * tcv.cin, "sf_vae_decode_frame: time conv must double the channels");
-      SF_TRY(conv(tcv, p.tc[i], T, H, W, 0, 0, p.ty[i], tcv.cin, 0, tcv.cin, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
-      SF_TRY(shift_history(p.tc[i], T, vol(1, H, W, tcv.cin), s));
+      SF_TRY(conv(tcv, p.tc[i], T, H, W, 0, c_tc, p.ty[i], tcv.cin, 0, tcv.cin, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+      SF_TRY(shift_history(p.tc[i], n_tc, T, Tmax, vol(1, H, W, tcv.cin), s, Tmax));
       up_in = p.ty[i];
       Tn = 2 * T;
     }
     // nearest 2x + Conv2d 3x3 per frame (vae.py:139-141), fused; its output feeds the next stage's first block, whose
     // norm1 rides in this convolution's epilogue when the halo kernel takes it
     const sf_vae_resblock& rn = res_at(m, i + 1, 0);
-    const NormOut nn = {p.blk[(i + 1) * m->res_per_stage].a1, rn.gamma1, rn.conv1.cin};
+    const NormOut nn = {p.blk[(i + 1) * m->res_per_stage].a1, rn.gamma1, rn.conv1.cin, hist_cursor(n, p.Tmax[i + 1]) + 2};
     const bool fuse = rn.conv1.cin == uc.cout && can_fuse_norm(uc, 2 * H, 2 * W);
     SF_TRY(conv(uc, up_in, Tn, 2 * H, 2 * W, 1, 0, p.xi[i + 1], uc.cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream, fuse ? &nn : nullptr));
     normed = fuse;
@@ -309,9 +339,10 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
   }
 
   // head (vae.py:455-471): RMS-norm, SiLU, causal conv to 3 channels; float, clamp
+  const int ch = hist_cursor(n, p.Tmax[L]);
   if (!normed)
-    SF_TRY(sf_rmsnorm_silu_cl(cur, m->head_gamma, p.head_in + 2 * vol(1, p.H[L], p.W[L], Ch), (long)T * p.H[L] * p.W[L], Ch, 1, stream));
-  SF_TRY(conv(m->head_conv, p.head_in, T, p.H[L], p.W[L], 0, 0, nullptr, 0, 0, 0, SF_CONV_BIAS_CLAMP_F32, nullptr, 0, pixels_out, stream));
-  SF_TRY(shift_history(p.head_in, T, vol(1, p.H[L], p.W[L], Ch), s));
+    SF_TRY(sf_rmsnorm_silu_cl(cur, m->head_gamma, p.head_in + (size_t)(ch + 2) * vol(1, p.H[L], p.W[L], Ch), (long)T * p.H[L] * p.W[L], Ch, 1, stream));
+  SF_TRY(conv(m->head_conv, p.head_in, T, p.H[L], p.W[L], 0, ch, nullptr, 0, 0, 0, SF_CONV_BIAS_CLAMP_F32, nullptr, 0, pixels_out, stream));
+  SF_TRY(shift_history(p.head_in, n, T, p.Tmax[L], vol(1, p.H[L], p.W[L], Ch), s));
   return 0;
 }

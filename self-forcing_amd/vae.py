@@ -53,6 +53,7 @@ class WanVAEDecoder:
         self._state: Dict[tuple, Tensor] = {}
         self._scratch: Dict[tuple, Tensor] = {}
         self._fresh = True     # no chunk decoded since the last clear_cache
+        self._nframes = 0      # latent frames decoded since then (positions the history windows: sf_vae_decode_frame)
         self._load(state_dict)
 
     # ---------------------------------------------------------------------------------
@@ -139,6 +140,7 @@ class WanVAEDecoder:
                 _lib.check(-1, "sf_vae_state_bytes")
             self._state[key] = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self._fresh = True
+            self._nframes = 0
         skey = (h, w, torch.cuda.current_stream(self.device).cuda_stream)
         if skey not in self._scratch:
             n = _lib.lib().sf_vae_scratch_bytes(C.byref(self.cmodel), h, w)
@@ -151,6 +153,7 @@ class WanVAEDecoder:
         for (h, w), st in self._state.items():
             _lib.check(_lib.lib().sf_vae_reset(C.byref(self.cmodel), st.data_ptr(), st.numel(), h, w, stream), "sf_vae_reset")
         self._fresh = True
+        self._nframes = 0
 
     def frames_out(self, latent_frames: int) -> int:
         tf = self.shape.temporal_factor
@@ -169,7 +172,8 @@ class WanVAEDecoder:
         t0 = 0
         for i in range(F):
             first = 1 if self._fresh else 0
-            torch.ops.sf_hip.vae_decode_frame(self._handle, state, scratch, z[i], out[t0:], h, w, bool(first))
+            torch.ops.sf_hip.vae_decode_frame(self._handle, state, scratch, z[i], out[t0:], h, w, self._nframes)
+            self._nframes += 1
             t0 += 1 if first else tf
             self._fresh = False
         return out
