@@ -36,6 +36,7 @@ struct HaloP {
   const bf16_t* bias;
   bf16_t* out;
   const bf16_t* resid;
+  float* out_f32;            // SF_CONV_BIAS_CLAMP_F32 (the 3-channel head): planar [T][Cout][H][W]
   bf16_t* norm_out;          // optional second output: SiLU(RMS_norm(y)) for the next convolution (tiles_n == 1 only)
   const bf16_t* norm_gamma;
   int norm_ld, norm_frame0;
@@ -243,6 +244,25 @@ __global__ __launch_bounds__(HALO_THREADS) void conv_halo_kernel(HaloP p) {
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
 
+  if (EPI == SF_CONV_BIAS_CLAMP_F32) {
+    // the decoder's head: Cout = 3 of the 32 columns are real; float, clamp(-1, 1), planar output (the layout
+    // decode_to_pixel returns: utils/wan_wrapper.py:113).  Lanes 0-15 hold channels 0-3 of their position.
+    if ((lane >> 4) == 0 && wn == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int h = h0 + wm * 4 + mt, w = w0 + i16;
+        if (h < p.H && w < p.W) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < p.Cout) {
+              const float v = acc[mt][0][j] + (float)p.bias[j];
+              p.out_f32[(((long)t * p.Cout + j) * p.H + h) * p.W + w] = fminf(fmaxf(v, -1.f), 1.f);
+            }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: bias (+ residual), through LDS so that every store covers whole 16-byte channel groups of a position
   constexpr int RBP = 64 * NT + 16;          // padded row bytes of the 256 x BN staging image
   char* obuf = smem;
@@ -329,6 +349,7 @@ int launch_halo(const HaloP& p, int tiles, int epi, hipStream_t s) {
   constexpr int LDS = PLANE_RING * PLANE_SLOT + 3 * TPC * 32 * NT * 64 + 8 * 1024;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert(256 * (64 * NT + 16) + 1024 <= LDS, "epilogue staging + norm factors fit the k-loop's LDS");
+  static_assert(NT == 3 || NT == 6, "bf16 epilogues: 96 or 192 columns per tile");
   static bool done = false;   // one-time registration of the kernels' LDS size (idempotent)
   if (!done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NT, TPC, SF_CONV_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -342,6 +363,17 @@ int launch_halo(const HaloP& p, int tiles, int epi, hipStream_t s) {
   return 0;
 }
 
+int launch_halo_head(const HaloP& p, int tiles, hipStream_t s) {   // NT = 1: 32 columns, Cout <= 4 of them real
+  constexpr int LDS = PLANE_RING * PLANE_SLOT + 3 * 3 * 32 * 64 + 8 * 1024;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<1, 3, SF_CONV_BIAS_CLAMP_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    done = true;
+  }
+  hipLaunchKernelGGL((conv_halo_kernel<1, 3, SF_CONV_BIAS_CLAMP_F32>), dim3(tiles), dim3(HALO_THREADS), LDS, s, p);
+  return 0;
+}
+
 }  // namespace
 
 // Returns 1 when the problem is outside this kernel's domain (the caller then uses conv_igemm; with a fused norm
@@ -349,14 +381,32 @@ int launch_halo(const HaloP& p, int tiles, int epi, hipStream_t s) {
 // output with bias / bias + residual, no channel -> frame interleave.
 __attribute__((visibility("hidden"))) int sf_conv_halo_launch(const sf_conv_args* a, void* stream) {
   if (!(a->kh == 3 && a->kw == 3) || a->interleave_c != 0 || a->Cin % 32 != 0) return 1;
+  if (a->H < 16 || a->W < 16) return 1;
+  const bool head = a->epilogue == SF_CONV_BIAS_CLAMP_F32 && a->Cout <= 4 && a->out_f32 && !a->norm_out;
+  if (head) {
+    HaloP p;
+    p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = (const bf16_t*)a->bias;
+    p.out = nullptr; p.resid = nullptr; p.out_f32 = a->out_f32; p.norm_out = nullptr; p.norm_gamma = nullptr; p.norm_ld = 0; p.norm_frame0 = 0;
+    p.H = a->H; p.W = a->W; p.Hin = a->Hin; p.Win = a->Win; p.up = a->upsample;
+    p.Cin = a->Cin; p.Cout = a->Cout; p.cpt = a->Cin / 32; p.kt = a->kt; p.t_off = a->t_in_offset;
+    p.ldw = a->ldw; p.ldo = 0; p.ldr = 0; p.out_frame0 = 0;
+    p.patches_h = (a->H + 15) / 16; p.patches_w = (a->W + 15) / 16; p.tiles_n = 1;
+    const long xbh = (long)(a->t_in_offset + a->Tout + a->kt - 1) * a->Hin * a->Win * a->Cin * 2;
+    if (xbh >= 0xFFFFFF00L) return 1;
+    p.x_bytes = (unsigned)xbh;
+    const long th = (long)a->Tout * p.patches_h * p.patches_w;
+    if (th >= (1L << 30)) return 1;
+    launch_halo_head(p, (int)th, (hipStream_t)stream);
+    return 0;
+  }
   if (a->epilogue != SF_CONV_BIAS && a->epilogue != SF_CONV_BIAS_RESID) return 1;
   if ((a->Cout & 7) != 0 || (a->out && (a->ldo & 7) != 0)) return 1;
   if (a->norm_out && !((a->Cout == 96 || a->Cout == 192) && a->norm_gamma && a->norm_ld >= a->Cout && (a->norm_ld & 7) == 0)) return 1;
   if (!a->out && !a->norm_out) return 1;
   const int nt = a->Cout % 192 == 0 ? 6 : a->Cout % 96 == 0 ? 3 : 0;
   if (nt == 0) return 1;
-  if (a->H < 16 || a->W < 16) return 1;
   HaloP p;
+  p.out_f32 = nullptr;
   p.x = (const bf16_t*)a->x; p.w = (const bf16_t*)a->w; p.bias = (const bf16_t*)a->bias;
   p.out = (bf16_t*)a->out; p.resid = (const bf16_t*)a->resid;
   p.norm_out = (bf16_t*)a->norm_out; p.norm_gamma = (const bf16_t*)a->norm_gamma; p.norm_ld = a->norm_ld; p.norm_frame0 = a->norm_frame_offset;

@@ -144,6 +144,23 @@ def test_head_conv_float_clamped_planar():
     assert (out.cpu() - ref).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("H,W", [(32, 48), (19, 37)])
+def test_head_conv_halo_structure(H, W):
+    """The 3-channel head (float, clamped, planar) in the halo kernel: 32-column tile of which 3 are real."""
+    g = torch.Generator().manual_seed(H + W)
+    cin, T = 96, 2
+    x = bf((cin, T + 2, H, W), g)
+    w, b = bf((3, cin, 3, 3, 3), g, 3.0 * (27 * cin) ** -0.5), bf((3,), g, 0.1)
+    ref = F.conv3d(F.pad(x.float()[None], (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].clamp(-1, 1).permute(1, 0, 2, 3)
+    xd, wd, bd = cl(x).to(DEV), repack_conv(w).to(DEV), b.to(DEV)
+    out = ops.conv_igemm(xd, wd, bd, (3, 3, 3), T, clamp_f32=True, structure="halo")
+    assert out.shape == (T, 3, H, W) and out.dtype == torch.float32
+    assert float((ref.abs() >= 1).float().mean()) > 0.02
+    assert (out.cpu() - ref).abs().max().item() < 2e-2
+    old = ops.conv_igemm(xd, wd, bd, (3, 3, 3), T, clamp_f32=True, structure="igemm")
+    assert (out - old).abs().max().item() < 2e-2
+
+
 def test_conv_padded_input_channels():
     """decoder.conv1: 16 latent channels zero-padded to 32."""
     g = torch.Generator().manual_seed(9)
