@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 6
+#define SF_HIP_ABI_VERSION 7
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -344,21 +344,30 @@ typedef struct sf_vae_model {             /* Decoder3d + conv2, vae.py:369-421, 
   sf_vae_conv head_conv;                  /* decoder.head.2 (cout = 3) */
 } sf_vae_model;
 
-/* Per-stream persistent state = the input volumes of every cached convolution (2 history frames + new frames, as a
- * window that slides through 2 + 4 T frames); scratch = everything else, reusable by any stream that does not overlap
- * in time. */
-size_t sf_vae_state_bytes(const sf_vae_model* model, int lat_h, int lat_w);
-size_t sf_vae_scratch_bytes(const sf_vae_model* model, int lat_h, int lat_w);
+/* Per-stream persistent state = the input volumes of every cached convolution: 2 history frames + new frames, as a
+ * window that slides through 2 + window_frames * T frames (T = the stage's frames per latent frame); scratch =
+ * everything else, reusable by any stream that does not overlap in time.  `window_frames` (2..64) is chosen by the
+ * caller once per state: a call decodes up to window_frames - 1 latent frames. */
+size_t sf_vae_state_bytes(const sf_vae_model* model, int lat_h, int lat_w, int window_frames);
+size_t sf_vae_scratch_bytes(const sf_vae_model* model, int lat_h, int lat_w, int window_frames);
 /* WanVAE_.clear_cache (vae.py:610-617): zero every history. */
-int sf_vae_reset(const sf_vae_model* model, void* state, size_t state_bytes, int lat_h, int lat_w, void* stream);
-/* One iteration of the per-latent-frame loop of decode / cached_decode (vae.py:566-578):
- * latent_frame [z][lat_h][lat_w] bf16 -> pixels [T][3][8 lat_h][8 lat_w] float32 in [-1, 1], T = 1 for
- * frame_index 0 (the frame that follows a reset), else 4 (vae.py:109-111, :134-137).  `frame_index` = the number of
- * latent frames decoded into `state` since its reset: it positions the history windows (the library keeps no state of
- * its own), so it must count up by one per call. */
-int sf_vae_decode_frame(const sf_vae_model* model, void* state, size_t state_bytes, void* scratch,
-                        size_t scratch_bytes, const void* latent_frame, int lat_h, int lat_w,
-                        int frame_index, float* pixels_out, void* stream);
+int sf_vae_reset(const sf_vae_model* model, void* state, size_t state_bytes, int lat_h, int lat_w,
+                 int window_frames, void* stream);
+/* n_frames iterations of the per-latent-frame loop of decode / cached_decode (vae.py:566-578) in one call:
+ * latent_frames [n_frames][z][lat_h][lat_w] bf16 -> pixels [T][3][8 lat_h][8 lat_w] float32 in [-1, 1], T = 1 for
+ * the frame that follows a reset (frame_index 0: decoded alone, vae.py:109-111, :134-137), else 4 n_frames.  The
+ * result is bit-identical to n_frames single-frame calls (the causal convolutions see the same inputs either way); a
+ * group fills the chip at the low-resolution stages.
+ * The library keeps no state of its own, so the caller says where the history windows are: `frame_index` = latent
+ * frames decoded into `state` since its reset; `window` = the slot (in latent frames) this call's frames take in the
+ * current lap of the sliding windows, window + n_frames <= window_frames; `history_at` = where the previous call
+ * ended: equal to `window` while the windows slide on, or -- when the caller restarts at window 0 because the frames
+ * no longer fit -- the previous lap's end slot, from which the two history frames of every volume are first copied
+ * to the front.  A caller's bookkeeping (self-forcing_amd/vae.py): slot = 0 after a reset; per call: if slot +
+ * n_frames > window_frames: (window, history_at) = (0, slot) else (slot, slot); slot = window + n_frames. */
+int sf_vae_decode_frames(const sf_vae_model* model, void* state, size_t state_bytes, void* scratch,
+                         size_t scratch_bytes, const void* latent_frames, int lat_h, int lat_w, int window_frames,
+                         int frame_index, int n_frames, int window, int history_at, float* pixels_out, void* stream);
 
 /* ==========================================================================================
  * umT5 text encoder (prompt token ids -> prompt embeddings): WanTextEncoder.forward after its tokenizer

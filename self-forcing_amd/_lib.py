@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # epilogue codes (enum sf_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
@@ -150,10 +150,10 @@ SIGNATURES = {
     "sf_rmsnorm_silu_cl": (C.c_int, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "sf_softmax_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp]),
     "sf_vae_prepare_latent": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "sf_vae_state_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i]),
-    "sf_vae_scratch_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i]),
-    "sf_vae_reset": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _i, _i, _vp]),
-    "sf_vae_decode_frame": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _vp, _sz, _vp, _i, _i, _i, _vp, _vp]),
+    "sf_vae_state_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i, _i]),
+    "sf_vae_scratch_bytes": (C.c_size_t, [C.POINTER(VaeModel), _i, _i, _i]),
+    "sf_vae_reset": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _i, _i, _i, _vp]),
+    "sf_vae_decode_frames": (C.c_int, [C.POINTER(VaeModel), _vp, _sz, _vp, _sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sf_embedding_gather": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sf_t5_softmax_bias": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sf_mul_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

@@ -58,4 +58,9 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u2));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with one v_exp_f32 and one v_rcp_f32 (no full-precision division: ~6 instructions instead of ~16); used
+// where the result is rounded to bf16 right away (the VAE's RMS_norm + SiLU passes, fused or not)
+__device__ __forceinline__ float silu_fast_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
 #endif

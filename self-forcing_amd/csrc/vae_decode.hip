@@ -1,6 +1,9 @@
-// One iteration of the Wan VAE's per-latent-frame decode loop as a single host call that enqueues
-// every kernel on the caller's stream: WanVAE_.decode / cached_decode (wan/modules/vae.py:556-593) ->
-// Decoder3d.forward with feat_cache (vae.py:423-472).
+// The Wan VAE's per-latent-frame decode loop -- WanVAE_.decode / cached_decode (wan/modules/vae.py:556-593) ->
+// Decoder3d.forward with feat_cache (vae.py:423-472) -- as a host call that enqueues every kernel on the caller's stream,
+// for ONE OR SEVERAL consecutive latent frames at a time: the causal convolutions see the same inputs whether the frames
+// arrive one per call (as the reference iterates) or together, every output element is computed by the same arithmetic in
+// the same order, so the result is bit-identical -- but a group of frames fills the chip at the low-resolution stages
+// (one frame of 60 x 104 is 28 patches) and leaves shorter tails at the others.
 //
 // Host-side only (no kernels here).  The reference threads a list of 32 cache tensors and an index
 // counter through the modules and re-concatenates [cache, x] in front of every convolution; here each
@@ -8,10 +11,11 @@
 // previous convolution's epilogue) writes the T new frames behind the two history frames, the convolution gathers its
 // temporal taps from frames t, t+1, t+2, and the last two frames become the next call's history (the cache update of
 // vae.py:206-216; for T = 1 that is the "borrow the last frame of the previous cache" branch).  The volume holds
-// 2 + 4 T frames and the window [history | new frames] SLIDES through it: the next call's history is where this
-// call's last two frames already are, and only every fourth call copies two frames back to the front (round 1
-// copied them after every convolution: 2756 copies and 5 % of a clip's decode time).  The window's position is a pure
-// function of the number of frames decoded since the reset, which the caller passes (no host state here).  A zeroed history IS the reference's zero
+// 2 + K T frames (K = `window_frames` latent frames, T = the stage's frames per latent frame) and the window
+// [history | new frames] SLIDES through it: the next call's history is where this call's last two frames already are;
+// when the next window would not fit the caller restarts at slot 0 and the two history frames are copied there first
+// (round 1 copied them after every convolution: 2756 copies and 5 % of a clip's decode time).  The window's position is
+// passed by the caller (`window`, `history_at`: no host state here).  A zeroed history IS the reference's zero
 // padding of the first chunk, so there is no first-chunk special case in the convolutions.  The two
 // quirks of Resample's bookkeeping (vae.py:104-132) are kept: the first chunk after a reset skips the
 // time convolution (one output frame), and its features never enter that convolution's history.
@@ -36,7 +40,7 @@ struct Carve {
 struct BlockBufs { char *a1, *a2; };
 
 struct Plan {
-  int n_stages, rps;
+  int n_stages, rps, K;
   int H[SF_VAE_MAX_STAGES], W[SF_VAE_MAX_STAGES], Tmax[SF_VAE_MAX_STAGES];
   // state
   char* c1_in;
@@ -55,30 +59,45 @@ struct Plan {
 
 inline size_t vol(int T, int H, int W, int C) { return (size_t)T * H * W * C * 2; }
 
-// Sliding history window of a cached convolution's input volume (capacity 2 + HIST_K * Tmax frames).  Call n (0-based,
-// counted from the reset) brings T_n = 1 (n == 0: the first chunk has one frame at every stage) or Tmax new frames.
-constexpr int HIST_K = 4;
-inline int hist_frames(int Tmax) { return 2 + HIST_K * Tmax; }
-inline int hist_cursor(int n, int Tmax, int T0 = 1) {   // first history frame of the volume's call n (its first call brings T0 frames)
-  int c = 0;
-  for (int k = 0; k < n; ++k) {
-    c += k == 0 ? T0 : Tmax;
-    if (c + 2 + Tmax > hist_frames(Tmax)) c = 0;  // the window of call k + 1 would not fit: it starts at the front again
-  }
-  return c;
+// Sliding history window of a cached convolution's input volume (capacity 2 + K * Tmax frames, K latent frames).
+// A lap = the calls between two restarts at slot 0; slot q of a lap holds the frames of the lap's q-th latent frame.
+// The lap that begins at the reset is special: its slot 0 is the first chunk, which has ONE frame at every stage
+// (vae.py:109-111) and never enters a time convolution's volume (the quirk of vae.py:104-132).
+inline int hist_frames(int K, int Tmax) { return 2 + K * Tmax; }
+inline int vol_off(int lap_start, int slot, int Tmax, bool time_conv) {   // first history frame of the window that starts at `slot`
+  if (lap_start != 0 || slot == 0) return slot * Tmax;
+  return time_conv ? (slot - 1) * Tmax : 1 + (slot - 1) * Tmax;
 }
-inline bool hist_wraps(int n, int Tmax, int T0 = 1) {    // does the window of call n + 1 start at the front again?
-  const int c = hist_cursor(n, Tmax, T0) + (n == 0 ? T0 : Tmax);
-  return c + 2 + Tmax > hist_frames(Tmax);
+
+struct Call {                 // one sf_vae_decode_frames call
+  int n, F, window, history_at;
+  hipStream_t s;
+  bool first_chunk() const { return n == 0; }
+  int off(int Tmax, bool tc = false) const { return vol_off(n - window, window, Tmax, tc); }
+};
+
+// the two history frames of a volume are where the previous call left them (slot `history_at` of ITS lap); a call that
+// restarts the window copies them to the front first (frame by frame: the ranges may overlap by one frame)
+int place_history(const Call& c, char* buf, int Tmax, size_t frame_bytes, bool tc = false) {
+  if (c.history_at == c.window) return 0;
+  if (tc && c.n - c.history_at == 0 && c.history_at <= 1) return 0;   // only the first chunk so far: this volume is still all zero
+  const int src = vol_off(c.n - c.history_at, c.history_at, Tmax, tc), dst = c.off(Tmax, tc);
+  for (int k = 0; k < 2; ++k) {
+    hipError_t e = hipMemcpyAsync(buf + (size_t)(dst + k) * frame_bytes, buf + (size_t)(src + k) * frame_bytes, frame_bytes, hipMemcpyDeviceToDevice, c.s);
+    SF_CHECK(e == hipSuccess, "sf_vae: history copy failed: %s", hipGetErrorString(e));
+  }
+  return 0;
 }
 
 const sf_vae_resblock& res_at(const sf_vae_model* m, int stage, int j) { return m->res_host[stage * m->res_per_stage + j]; }
 
-Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w) {
+Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w, int K) {
   Plan p;
   memset(&p, 0, sizeof(p));
   p.n_stages = m->n_stages;
   p.rps = m->res_per_stage;
+  p.K = K;
+  const int Fmax = K - 1;        // latent frames per call (the lap that begins at the reset holds the first chunk + Fmax)
   int T = 1;
   for (int i = 0; i < m->n_stages; ++i) {
     p.H[i] = h << i;
@@ -87,33 +106,33 @@ Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w) 
     if (i + 1 < m->n_stages && m->temporal_up[i]) T *= 2;
   }
   Carve st(state);
-  p.c1_in = st.take(vol(hist_frames(1), h, w, m->conv1.cin));
+  p.c1_in = st.take(vol(hist_frames(K, 1), h, w, m->conv1.cin));
   const int C0 = m->conv1.cout;
-  p.mid0.a1 = st.take(vol(hist_frames(1), h, w, C0)); p.mid0.a2 = st.take(vol(hist_frames(1), h, w, C0));
-  p.mid2.a1 = st.take(vol(hist_frames(1), h, w, C0)); p.mid2.a2 = st.take(vol(hist_frames(1), h, w, C0));
+  p.mid0.a1 = st.take(vol(hist_frames(K, 1), h, w, C0)); p.mid0.a2 = st.take(vol(hist_frames(K, 1), h, w, C0));
+  p.mid2.a1 = st.take(vol(hist_frames(K, 1), h, w, C0)); p.mid2.a2 = st.take(vol(hist_frames(K, 1), h, w, C0));
   for (int i = 0; i < m->n_stages; ++i) {
     for (int j = 0; j < m->res_per_stage; ++j) {
       const sf_vae_resblock& r = res_at(m, i, j);
       BlockBufs& b = p.blk[i * m->res_per_stage + j];
-      b.a1 = st.take(vol(hist_frames(p.Tmax[i]), p.H[i], p.W[i], r.conv1.cin));
-      b.a2 = st.take(vol(hist_frames(p.Tmax[i]), p.H[i], p.W[i], r.conv2.cin));
+      b.a1 = st.take(vol(hist_frames(K, p.Tmax[i]), p.H[i], p.W[i], r.conv1.cin));
+      b.a2 = st.take(vol(hist_frames(K, p.Tmax[i]), p.H[i], p.W[i], r.conv2.cin));
     }
-    p.tc[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? st.take(vol(hist_frames(p.Tmax[i]), p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
+    p.tc[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? st.take(vol(hist_frames(K, p.Tmax[i]), p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
   }
   const int L = m->n_stages - 1;
-  p.head_in = st.take(vol(hist_frames(p.Tmax[L]), p.H[L], p.W[L], m->head_conv.cin));
+  p.head_in = st.take(vol(hist_frames(K, p.Tmax[L]), p.H[L], p.W[L], m->head_conv.cin));
   p.state_total = st.off;
 
   Carve sc(scratch);
-  size_t y1_max = vol(1, h, w, C0), sc_max = 256;
+  size_t y1_max = vol(Fmax, h, w, C0), sc_max = 256;
   for (int i = 0; i < m->n_stages; ++i) {
     const int cin = res_at(m, i, 0).conv1.cin, cout = res_at(m, i, 0).conv1.cout;
-    p.xi[i] = sc.take(vol(p.Tmax[i], p.H[i], p.W[i], i == 0 ? C0 : cin));
-    p.x[i] = sc.take(vol(p.Tmax[i], p.H[i], p.W[i], cout));
-    p.ty[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? sc.take(vol(2 * p.Tmax[i], p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
+    p.xi[i] = sc.take(vol(Fmax * p.Tmax[i], p.H[i], p.W[i], i == 0 ? C0 : cin));
+    p.x[i] = sc.take(vol(Fmax * p.Tmax[i], p.H[i], p.W[i], cout));
+    p.ty[i] = (i + 1 < m->n_stages && m->time_conv[i].w) ? sc.take(vol(2 * Fmax * p.Tmax[i], p.H[i], p.W[i], m->time_conv[i].cin)) : nullptr;
     for (int j = 0; j < m->res_per_stage; ++j) {
       const sf_vae_resblock& r = res_at(m, i, j);
-      const size_t v = vol(p.Tmax[i], p.H[i], p.W[i], r.conv1.cout);
+      const size_t v = vol(Fmax * p.Tmax[i], p.H[i], p.W[i], r.conv1.cout);
       if (v > y1_max) y1_max = v;
       if (r.shortcut.w && v > sc_max) sc_max = v;
     }
@@ -132,8 +151,9 @@ Plan make_plan(const sf_vae_model* m, void* state, void* scratch, int h, int w) 
   return p;
 }
 
-int check_model(const sf_vae_model* m, int h, int w) {
+int check_model(const sf_vae_model* m, int h, int w, int K) {
   SF_CHECK(m != nullptr, "sf_vae: null model");
+  SF_CHECK(K >= 2 && K <= 64, "sf_vae: window_frames %d (2..64: a call decodes up to window_frames - 1 latent frames)", K);
   SF_CHECK(m->n_stages >= 1 && m->n_stages <= SF_VAE_MAX_STAGES && m->res_per_stage >= 1 && m->res_per_stage <= 8, "sf_vae: bad stage counts");
   SF_CHECK(m->res_host && m->conv1.w && m->head_conv.w && m->latent_mean && m->latent_std && m->conv2_w && m->conv2_b, "sf_vae: model has null weights");
   SF_CHECK(h > 0 && w > 0 && (h * w) % 4 == 0, "sf_vae: latent size %dx%d (h*w must be a multiple of 4)", h, w);
@@ -175,27 +195,16 @@ int gemm(const void* a, int lda, const void* w, int ldw, const void* bias, void*
   return sf_gemm_bf16(&g, stream);
 }
 
-// the cache update after call n: the window slides by the call's T frames; only when the next window would not fit are
-// the last two frames copied to the front
-int shift_history(char* buf, int n, int T, int Tmax, size_t frame_bytes, hipStream_t s, int T0 = 1) {
-  if (!hist_wraps(n, Tmax, T0)) return 0;
-  const int c = hist_cursor(n, Tmax, T0);
-  hipError_t e = hipMemcpyAsync(buf, buf + (size_t)(c + T) * frame_bytes, 2 * frame_bytes, hipMemcpyDeviceToDevice, s);
-  SF_CHECK(e == hipSuccess, "sf_vae: history copy failed: %s", hipGetErrorString(e));
-  return 0;
-}
-
 // ResidualBlock.forward (vae.py:202-221) on T frames of H x W.  `in_normed`: the producer of x_in already wrote
 // SiLU(RMS_norm(x_in)) into conv1's input volume (fused epilogue); `next`: where (and with which gamma) this block's
 // output should ALSO be written normalised -- the next block's conv1 input or the head's --, if its conv2 can do that.
 // Returns through *out_normed whether it did.
-int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, int n, int T, int Tmax, int H, int W,
+int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const char* x_in, char* out, const Call& cl, int T, int Tmax, int H, int W,
              void* stream, bool in_normed = false, const NormOut* next = nullptr, bool* out_normed = nullptr) {
-  hipStream_t s = (hipStream_t)stream;
   const long rows = (long)T * H * W;
   const int cin = r.conv1.cin, cout = r.conv1.cout;
   const size_t f1 = vol(1, H, W, cin), f2 = vol(1, H, W, cout);
-  const int c = hist_cursor(n, Tmax);                 // both volumes of the block slide alike
+  const int c = cl.off(Tmax);                         // both volumes of the block slide alike
   if (!in_normed) SF_TRY(sf_rmsnorm_silu_cl(x_in, r.gamma1, b.a1 + (size_t)(c + 2) * f1, rows, cin, 1, stream));
   if (can_fuse_norm(r.conv1, H, W)) {   // conv1's raw output is only ever read by the norm in front of conv2
     const NormOut n2 = {b.a2, r.gamma2, cout, c + 2};
@@ -204,7 +213,6 @@ int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const 
     SF_TRY(conv(r.conv1, b.a1, T, H, W, 0, c, p.y1, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
     SF_TRY(sf_rmsnorm_silu_cl(p.y1, r.gamma2, b.a2 + (size_t)(c + 2) * f2, rows, cout, 1, stream));
   }
-  SF_TRY(shift_history(b.a1, n, T, Tmax, f1, s));
   const char* resid = x_in;
   if (r.shortcut.w) {
     SF_TRY(conv(r.shortcut, x_in, T, H, W, 0, 0, p.sc, cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
@@ -213,7 +221,6 @@ int resblock(const sf_vae_resblock& r, const BlockBufs& b, const Plan& p, const 
   const bool fuse_next = next && next->ld == r.conv2.cout && can_fuse_norm(r.conv2, H, W);
   SF_TRY(conv(r.conv2, b.a2, T, H, W, 0, c, out, cout, 0, 0, SF_CONV_BIAS_RESID, resid, cout, nullptr, stream, fuse_next ? next : nullptr));
   if (out_normed) *out_normed = fuse_next;
-  SF_TRY(shift_history(b.a2, n, T, Tmax, f2, s));
   return 0;
 }
 
@@ -237,80 +244,103 @@ int attention_block(const sf_vae_model* m, const Plan& p, char* x, int n, int C,
 
 }  // namespace
 
-extern "C" size_t sf_vae_state_bytes(const sf_vae_model* m, int h, int w) {
-  if (check_model(m, h, w) != 0) return 0;
-  return make_plan(m, nullptr, nullptr, h, w).state_total;
+extern "C" size_t sf_vae_state_bytes(const sf_vae_model* m, int h, int w, int window_frames) {
+  if (check_model(m, h, w, window_frames) != 0) return 0;
+  return make_plan(m, nullptr, nullptr, h, w, window_frames).state_total;
 }
 
-extern "C" size_t sf_vae_scratch_bytes(const sf_vae_model* m, int h, int w) {
-  if (check_model(m, h, w) != 0) return 0;
-  return make_plan(m, nullptr, nullptr, h, w).scratch_total;
+extern "C" size_t sf_vae_scratch_bytes(const sf_vae_model* m, int h, int w, int window_frames) {
+  if (check_model(m, h, w, window_frames) != 0) return 0;
+  return make_plan(m, nullptr, nullptr, h, w, window_frames).scratch_total;
 }
 
-extern "C" int sf_vae_reset(const sf_vae_model* m, void* state, size_t state_bytes, int h, int w, void* stream) {
-  SF_TRY(check_model(m, h, w));
-  const Plan p = make_plan(m, nullptr, nullptr, h, w);
+extern "C" int sf_vae_reset(const sf_vae_model* m, void* state, size_t state_bytes, int h, int w, int window_frames, void* stream) {
+  SF_TRY(check_model(m, h, w, window_frames));
+  const Plan p = make_plan(m, nullptr, nullptr, h, w, window_frames);
   SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_reset: state too small (%zu < %zu)", state_bytes, p.state_total);
   hipError_t e = hipMemsetAsync(state, 0, p.state_total, (hipStream_t)stream);
   SF_CHECK(e == hipSuccess, "sf_vae_reset: memset failed: %s", hipGetErrorString(e));
   return 0;
 }
 
-extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
-                                   const void* latent_frame, int h, int w, int frame_index, float* pixels_out, void* stream) {
-  SF_TRY(check_model(m, h, w));
-  SF_CHECK(latent_frame && pixels_out, "sf_vae_decode_frame: null tensor");
-  SF_CHECK(frame_index >= 0 && frame_index < (1 << 20), "sf_vae_decode_frame: frame_index %d (latent frames decoded since the reset)", frame_index);
-  const int n = frame_index;
-  const bool first_chunk = n == 0;
-  const Plan p = make_plan(m, state, scratch, h, w);
-  SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_decode_frame: state too small (%zu < %zu)", state_bytes, p.state_total);
-  SF_CHECK(scratch && scratch_bytes >= p.scratch_total, "sf_vae_decode_frame: scratch too small (%zu < %zu)", scratch_bytes, p.scratch_total);
-  hipStream_t s = (hipStream_t)stream;
+extern "C" int sf_vae_decode_frames(const sf_vae_model* m, void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
+                                    const void* latent_frames, int h, int w, int window_frames, int frame_index, int n_frames,
+                                    int window, int history_at, float* pixels_out, void* stream) {
+  SF_TRY(check_model(m, h, w, window_frames));
+  SF_CHECK(latent_frames && pixels_out, "sf_vae_decode_frames: null tensor");
+  const int K = window_frames, F = n_frames;
+  SF_CHECK(frame_index >= 0 && frame_index < (1 << 24), "sf_vae_decode_frames: frame_index %d (latent frames decoded since the reset)", frame_index);
+  SF_CHECK(F >= 1 && F <= K - 1, "sf_vae_decode_frames: n_frames %d (1..window_frames - 1 = %d)", F, K - 1);
+  SF_CHECK(frame_index > 0 || (F == 1 && window == 0 && history_at == 0),
+           "sf_vae_decode_frames: the frame that follows a reset is decoded alone at window 0 (it has one output frame: vae.py:109-111)");
+  SF_CHECK(window >= 0 && window + F <= K && window <= frame_index, "sf_vae_decode_frames: window %d + %d frames does not fit %d slots", window, F, K);
+  SF_CHECK(history_at == window || (window == 0 && history_at >= 1 && history_at <= K && history_at <= frame_index),
+           "sf_vae_decode_frames: history_at %d (== window, or the previous lap's end when the window restarts at 0)", history_at);
+  const Call cl = {frame_index, F, window, history_at, (hipStream_t)stream};
+  const bool first_chunk = cl.first_chunk();
+  const Plan p = make_plan(m, state, scratch, h, w, K);
+  SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_decode_frames: state too small (%zu < %zu)", state_bytes, p.state_total);
+  SF_CHECK(scratch && scratch_bytes >= p.scratch_total, "sf_vae_decode_frames: scratch too small (%zu < %zu)", scratch_bytes, p.scratch_total);
   const int C0 = m->conv1.cout;
-
-  // un-scale + conv2 (1x1x1) -> the new frame of decoder.conv1's input volume; conv1 (vae.py:425-438)
-  const size_t f_in = vol(1, h, w, m->conv1.cin);
-  const int c1 = hist_cursor(n, 1);
-  SF_TRY(sf_vae_prepare_latent(latent_frame, m->latent_mean, m->latent_std, m->conv2_w, m->conv2_b, p.c1_in + (size_t)(c1 + 2) * f_in, m->z_dim, h, w,
-                               m->conv1.cin, stream));
-  SF_TRY(conv(m->conv1, p.c1_in, 1, h, w, 0, c1, p.xi[0], C0, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
-  SF_TRY(shift_history(p.c1_in, n, 1, 1, f_in, s));
-
-  // middle (vae.py:441-445): res, attention, res -- all on the one latent-rate frame
-  SF_CHECK(res_at(m, 0, 0).conv1.cin == C0 && res_at(m, 0, 0).conv1.cout == C0, "sf_vae_decode_frame: stage 0 must keep the decoder width");
-  SF_TRY(resblock(m->mid0, p.mid0, p, p.xi[0], p.x[0], n, 1, 1, h, w, stream));
-  SF_TRY(attention_block(m, p, p.x[0], h * w, C0, stream));
-  SF_TRY(resblock(m->mid2, p.mid2, p, p.x[0], p.x[0], n, 1, 1, h, w, stream));
-
-  // upsample stages (vae.py:448-452).  `normed`: the next consumer's input volume already holds SiLU(RMS_norm(cur))
-  int T = 1;
-  const char* cur = p.x[0];   // the stage's running activation
-  bool normed = false;
   const int L = m->n_stages - 1;
   const int Ch = m->head_conv.cin;
+
+  // a restarted window: every volume's two history frames move to the front BEFORE any producer writes new frames
+  if (history_at != window) {
+    SF_TRY(place_history(cl, p.c1_in, 1, vol(1, h, w, m->conv1.cin)));
+    SF_TRY(place_history(cl, p.mid0.a1, 1, vol(1, h, w, C0))); SF_TRY(place_history(cl, p.mid0.a2, 1, vol(1, h, w, C0)));
+    SF_TRY(place_history(cl, p.mid2.a1, 1, vol(1, h, w, C0))); SF_TRY(place_history(cl, p.mid2.a2, 1, vol(1, h, w, C0)));
+    for (int i = 0; i < m->n_stages; ++i) {
+      for (int j = 0; j < m->res_per_stage; ++j) {
+        const sf_vae_resblock& r = res_at(m, i, j);
+        const BlockBufs& b = p.blk[i * m->res_per_stage + j];
+        SF_TRY(place_history(cl, b.a1, p.Tmax[i], vol(1, p.H[i], p.W[i], r.conv1.cin)));
+        SF_TRY(place_history(cl, b.a2, p.Tmax[i], vol(1, p.H[i], p.W[i], r.conv2.cin)));
+      }
+      if (p.tc[i]) SF_TRY(place_history(cl, p.tc[i], p.Tmax[i], vol(1, p.H[i], p.W[i], m->time_conv[i].cin), true));
+    }
+    SF_TRY(place_history(cl, p.head_in, p.Tmax[L], vol(1, p.H[L], p.W[L], Ch)));
+  }
+
+  // un-scale + conv2 (1x1x1) -> the new frames of decoder.conv1's input volume; conv1 (vae.py:425-438)
+  const size_t f_in = vol(1, h, w, m->conv1.cin);
+  const int c1 = cl.off(1);
+  for (int f = 0; f < F; ++f)
+    SF_TRY(sf_vae_prepare_latent((const char*)latent_frames + (size_t)f * m->z_dim * h * w * 2, m->latent_mean, m->latent_std, m->conv2_w, m->conv2_b,
+                                 p.c1_in + (size_t)(c1 + 2 + f) * f_in, m->z_dim, h, w, m->conv1.cin, stream));
+  SF_TRY(conv(m->conv1, p.c1_in, F, h, w, 0, c1, p.xi[0], C0, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
+
+  // middle (vae.py:441-445): res, attention (per frame), res -- on the latent-rate frames
+  SF_CHECK(res_at(m, 0, 0).conv1.cin == C0 && res_at(m, 0, 0).conv1.cout == C0, "sf_vae_decode_frames: stage 0 must keep the decoder width");
+  SF_TRY(resblock(m->mid0, p.mid0, p, p.xi[0], p.x[0], cl, F, 1, h, w, stream));
+  for (int f = 0; f < F; ++f) SF_TRY(attention_block(m, p, p.x[0] + (size_t)f * vol(1, h, w, C0), h * w, C0, stream));
+  SF_TRY(resblock(m->mid2, p.mid2, p, p.x[0], p.x[0], cl, F, 1, h, w, stream));
+
+  // upsample stages (vae.py:448-452).  `normed`: the next consumer's input volume already holds SiLU(RMS_norm(cur))
+  int T = F;
+  const char* cur = p.x[0];   // the stage's running activation
+  bool normed = false;
   for (int i = 0; i < m->n_stages; ++i) {
     const int H = p.H[i], W = p.W[i], Tmax = p.Tmax[i];
     const bool has_up = i + 1 < m->n_stages;
     const bool has_tc = has_up && m->time_conv[i].w != nullptr;
-    SF_CHECK(T == (first_chunk ? 1 : Tmax), "sf_vae_decode_frame: stage %d expects %d frames, has %d", i, first_chunk ? 1 : Tmax, T);
-    // the time convolution's volume only counts the calls in which it runs (not the first chunk, whose features never enter
-    // its history: the quirk of vae.py:104-132); all of them bring Tmax frames
-    const int n_tc = n - 1, c_tc = first_chunk ? 0 : hist_cursor(n_tc, Tmax, Tmax);
+    SF_CHECK(T == (first_chunk ? 1 : F * Tmax), "sf_vae_decode_frames: stage %d expects %d frames, has %d", i, first_chunk ? 1 : F * Tmax, T);
+    const int c_st = cl.off(Tmax), c_tc = cl.off(Tmax, true);
     for (int j = 0; j < m->res_per_stage; ++j) {
       const sf_vae_resblock& r = res_at(m, i, j);
       char* out = p.x[i];
-      if (j == m->res_per_stage - 1 && has_tc) out = p.tc[i] + (size_t)(c_tc + 2) * vol(1, H, W, m->time_conv[i].cin);   // feeds the time conv
+      if (j == m->res_per_stage - 1 && has_tc && !first_chunk)
+        out = p.tc[i] + (size_t)(c_tc + 2) * vol(1, H, W, m->time_conv[i].cin);   // feeds the time conv (not the first chunk: vae.py:104-132)
       // who reads this block's output through a norm: the next block of the stage, or (last block of the last stage) the head
       NormOut next = {nullptr, nullptr, 0, 0};
       if (j + 1 < m->res_per_stage) {
         const sf_vae_resblock& rn = res_at(m, i, j + 1);
-        next = {p.blk[i * m->res_per_stage + j + 1].a1, rn.gamma1, rn.conv1.cin, hist_cursor(n, Tmax) + 2};
+        next = {p.blk[i * m->res_per_stage + j + 1].a1, rn.gamma1, rn.conv1.cin, c_st + 2};
       } else if (!has_up) {
-        next = {p.head_in, m->head_gamma, Ch, hist_cursor(n, Tmax) + 2};
+        next = {p.head_in, m->head_gamma, Ch, c_st + 2};
       }
       bool out_normed = false;
-      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, n, T, Tmax, H, W, stream, normed, next.dst ? &next : nullptr, &out_normed));
+      SF_TRY(resblock(r, p.blk[i * m->res_per_stage + j], p, cur, out, cl, T, Tmax, H, W, stream, normed, next.dst ? &next : nullptr, &out_normed));
       normed = out_normed;
       cur = out;
     }
@@ -321,16 +351,15 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
     if (has_tc && !first_chunk) {
       // Resample 'upsample3d' (vae.py:112-137): (3,1,1) causal conv C -> 2C, channel halves -> frames 2t, 2t+1
       const sf_vae_conv& tcv = m->time_conv[i];
-      SF_CHECK(tcv.cout == 2 * tcv.cin, "sf_vae_decode_frame: time conv must double the channels");
+      SF_CHECK(tcv.cout == 2 * tcv.cin, "sf_vae_decode_frames: time conv must double the channels");
       SF_TRY(conv(tcv, p.tc[i], T, H, W, 0, c_tc, p.ty[i], tcv.cin, 0, tcv.cin, SF_CONV_BIAS, nullptr, 0, nullptr, stream));
-      SF_TRY(shift_history(p.tc[i], n_tc, T, Tmax, vol(1, H, W, tcv.cin), s, Tmax));
       up_in = p.ty[i];
       Tn = 2 * T;
     }
     // nearest 2x + Conv2d 3x3 per frame (vae.py:139-141), fused; its output feeds the next stage's first block, whose
     // norm1 rides in this convolution's epilogue when the halo kernel takes it
     const sf_vae_resblock& rn = res_at(m, i + 1, 0);
-    const NormOut nn = {p.blk[(i + 1) * m->res_per_stage].a1, rn.gamma1, rn.conv1.cin, hist_cursor(n, p.Tmax[i + 1]) + 2};
+    const NormOut nn = {p.blk[(i + 1) * m->res_per_stage].a1, rn.gamma1, rn.conv1.cin, cl.off(p.Tmax[i + 1]) + 2};
     const bool fuse = rn.conv1.cin == uc.cout && can_fuse_norm(uc, 2 * H, 2 * W);
     SF_TRY(conv(uc, up_in, Tn, 2 * H, 2 * W, 1, 0, p.xi[i + 1], uc.cout, 0, 0, SF_CONV_BIAS, nullptr, 0, nullptr, stream, fuse ? &nn : nullptr));
     normed = fuse;
@@ -339,10 +368,9 @@ extern "C" int sf_vae_decode_frame(const sf_vae_model* m, void* state, size_t st
   }
 
   // head (vae.py:455-471): RMS-norm, SiLU, causal conv to 3 channels; float, clamp
-  const int ch = hist_cursor(n, p.Tmax[L]);
+  const int ch = cl.off(p.Tmax[L]);
   if (!normed)
     SF_TRY(sf_rmsnorm_silu_cl(cur, m->head_gamma, p.head_in + (size_t)(ch + 2) * vol(1, p.H[L], p.W[L], Ch), (long)T * p.H[L] * p.W[L], Ch, 1, stream));
   SF_TRY(conv(m->head_conv, p.head_in, T, p.H[L], p.W[L], 0, ch, nullptr, 0, 0, 0, SF_CONV_BIAS_CLAMP_F32, nullptr, 0, pixels_out, stream));
-  SF_TRY(shift_history(p.head_in, n, T, p.Tmax[L], vol(1, p.H[L], p.W[L], Ch), s));
   return 0;
 }

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const bf16_t* __restr
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float y = v[j] * inv * (float)g[j];
-    if (silu) y = silu_f(y);
+    if (silu) y = silu_fast_f(y);
     o8[j] = (bf16_t)y;
   }
   *reinterpret_cast<bf16x8*>(out + row * C + sub * 8) = o8;

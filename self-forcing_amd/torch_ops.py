@@ -15,7 +15,7 @@ tracing, and is opaque-but-legal to `torch.compile` -- which the reference's sec
     sf_hip::add_noise(x0, eps, timestep, sigmas, timesteps) -> out
     sf_hip::dit_forward(model, noisy, timestep, prompt_embeds?, add_condition?, k_cache![], v_cache![], ck_cache![],
                         cv_cache![], workspace!, evict_scratch!?, ...) -> (flow, x0)
-    sf_hip::vae_decode_frame(model, state!, scratch!, z, out!, h, w, frame_index) -> ()
+    sf_hip::vae_decode_frames(model, state!, scratch!, z, out!, h, w, window_frames, frame_index, window, history_at) -> ()
     sf_hip::t5_encode(model, ids, mask, buckets, workspace!) -> out
 
 Models (weights + C descriptors) are Python objects that own device memory; operators take an integer HANDLE from
@@ -273,19 +273,22 @@ def _(model, noisy, timestep, prompt_embeds, add_condition, k_cache, v_cache, ck
 
 
 # ------------------------------------------------------------------------------------------ VAE decode / T5 encode
-@custom_op(f"{NAMESPACE}::vae_decode_frame", mutates_args=("state", "scratch", "out"))
-def vae_decode_frame(model: int, state: Tensor, scratch: Tensor, z: Tensor, out: Tensor, h: int, w: int, frame_index: int) -> None:
-    """One latent frame z [z_dim, h, w] -> 1 (frame_index 0) or 4 pixel frames written to the front of `out` (float32
-    [T, 3, 8h, 8w]); `state` carries every convolution's two-frame history between calls; `frame_index` counts the
-    latent frames decoded into it since its reset (sf_vae_decode_frame)."""
+@custom_op(f"{NAMESPACE}::vae_decode_frames", mutates_args=("state", "scratch", "out"))
+def vae_decode_frames(model: int, state: Tensor, scratch: Tensor, z: Tensor, out: Tensor, h: int, w: int, window_frames: int,
+                      frame_index: int, window: int, history_at: int) -> None:
+    """Consecutive latent frames z [F, z_dim, h, w] -> 1 (frame_index 0: F = 1) or 4 F pixel frames written to the front
+    of `out` (float32 [T, 3, 8h, 8w]); `state` carries every convolution's two-frame history between calls; `frame_index`
+    counts the latent frames decoded into it since its reset, `window` / `history_at` place the sliding history windows
+    (sf_vae_decode_frames in include/sf_hip.h; `WanVAEDecoder.cached_decode` does the bookkeeping)."""
     m = _model(model)
     _need_gpu(z, "z")
     _need_gpu(out, "out", torch.float32)
-    if not z.is_contiguous() or not out.is_contiguous():
-        raise ValueError("vae_decode_frame: contiguous tensors expected")
-    _lib.check(_lib.lib().sf_vae_decode_frame(C.byref(m.cmodel), state.data_ptr(), state.numel(), scratch.data_ptr(), scratch.numel(),
-                                              z.data_ptr(), h, w, frame_index, out.data_ptr(), _stream(z)),
-               "sf_vae_decode_frame")
+    if z.dim() != 4 or not z.is_contiguous() or not out.is_contiguous():
+        raise ValueError("vae_decode_frames: contiguous z [F, z_dim, h, w] and out expected")
+    _lib.check(_lib.lib().sf_vae_decode_frames(C.byref(m.cmodel), state.data_ptr(), state.numel(), scratch.data_ptr(), scratch.numel(),
+                                               z.data_ptr(), h, w, window_frames, frame_index, z.shape[0], window, history_at,
+                                               out.data_ptr(), _stream(z)),
+               "sf_vae_decode_frames")
 
 
 @custom_op(f"{NAMESPACE}::t5_encode", mutates_args=("workspace",))
@@ -307,4 +310,4 @@ def _(model, ids, mask, buckets, workspace):
     return ids.new_empty((ids.shape[0], ids.shape[1], _model(model).shape.dim), dtype=torch.bfloat16)
 
 
-OPS = ("attention", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "vae_decode_frame", "t5_encode")
+OPS = ("attention", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "vae_decode_frames", "t5_encode")

@@ -7,7 +7,7 @@ Mirrors `utils/wan_wrapper.py:56-117` for the decode direction only:
     vae.model.clear_cache()                                    # inference.py:183
 
 Every kernel is in csrc/ (conv_igemm.hip, vae_elementwise.hip, gemm_bf16.hip) and one latent frame is ONE
-C call (`sf_vae_decode_frame`).  There is no eager/CPU fallback.  `encode_to_latent` (used only by
+C call (`sf_vae_decode_frames`).  There is no eager/CPU fallback.  `encode_to_latent` (used only by
 `--i2v`, inference.py:145) is not on this path and raises.
 """
 from __future__ import annotations
@@ -46,14 +46,19 @@ class WanVAEDecoder:
     (the convolution histories of one stream).  Counterpart of `WanVAE_` (wan/modules/vae.py:478-617)
     for `decode` / `cached_decode` / `clear_cache`."""
 
-    def __init__(self, shape: VaeShape, state_dict: Dict[str, Tensor], device):
+    def __init__(self, shape: VaeShape, state_dict: Dict[str, Tensor], device, frames_per_call: int = 4):
+        if not 1 <= frames_per_call <= 63:
+            raise ValueError("frames_per_call must be in 1..63")
         self.shape = shape
         self.device = torch.device(device)
+        self.frames_per_call = frames_per_call          # latent frames handed to one C call (any value gives the same bits)
+        self.window_frames = frames_per_call + 1        # slots of the sliding history windows (the first chunk + one group)
         self._keep: List[Tensor] = []
         self._state: Dict[tuple, Tensor] = {}
         self._scratch: Dict[tuple, Tensor] = {}
         self._fresh = True     # no chunk decoded since the last clear_cache
-        self._nframes = 0      # latent frames decoded since then (positions the history windows: sf_vae_decode_frame)
+        self._nframes = 0      # latent frames decoded since then
+        self._slot = 0         # ... of them in the current lap of the sliding history windows (sf_vae_decode_frames)
         self._load(state_dict)
 
     # ---------------------------------------------------------------------------------
@@ -134,16 +139,20 @@ class WanVAEDecoder:
     # ---------------------------------------------------------------------------------
     def _buffers(self, h: int, w: int):
         key = (h, w)
+        sf, tf = self.shape.spatial_factor, self.shape.temporal_factor
+        if (2 + self.window_frames * tf) * (sf * h) * (sf * w) * self.cmodel.head_conv.cin * 2 >= 0xFFFFFF00:
+            raise ValueError(f"frames_per_call={self.frames_per_call} at {sf * h}x{sf * w}: a convolution's input volume would pass 4 GiB "
+                             "(the kernels address a volume through one 32-bit-ranged buffer descriptor); use fewer frames per call")
         if key not in self._state:
-            n = _lib.lib().sf_vae_state_bytes(C.byref(self.cmodel), h, w)
+            n = _lib.lib().sf_vae_state_bytes(C.byref(self.cmodel), h, w, self.window_frames)
             if n == 0:
                 _lib.check(-1, "sf_vae_state_bytes")
             self._state[key] = torch.zeros(n, dtype=torch.uint8, device=self.device)
             self._fresh = True
-            self._nframes = 0
+            self._nframes = self._slot = 0
         skey = (h, w, torch.cuda.current_stream(self.device).cuda_stream)
         if skey not in self._scratch:
-            n = _lib.lib().sf_vae_scratch_bytes(C.byref(self.cmodel), h, w)
+            n = _lib.lib().sf_vae_scratch_bytes(C.byref(self.cmodel), h, w, self.window_frames)
             self._scratch[skey] = torch.empty(n, dtype=torch.uint8, device=self.device)
         return self._state[key], self._scratch[skey]
 
@@ -151,9 +160,9 @@ class WanVAEDecoder:
         """`WanVAE_.clear_cache` (vae.py:610-617): forget every convolution's history."""
         stream = torch.cuda.current_stream(self.device).cuda_stream if self._state else None
         for (h, w), st in self._state.items():
-            _lib.check(_lib.lib().sf_vae_reset(C.byref(self.cmodel), st.data_ptr(), st.numel(), h, w, stream), "sf_vae_reset")
+            _lib.check(_lib.lib().sf_vae_reset(C.byref(self.cmodel), st.data_ptr(), st.numel(), h, w, self.window_frames, stream), "sf_vae_reset")
         self._fresh = True
-        self._nframes = 0
+        self._nframes = self._slot = 0
 
     def frames_out(self, latent_frames: int) -> int:
         tf = self.shape.temporal_factor
@@ -169,12 +178,22 @@ class WanVAEDecoder:
         state, scratch = self._buffers(h, w)
         sf, tf = self.shape.spatial_factor, self.shape.temporal_factor
         out = torch.empty(self.frames_out(F), 3, sf * h, sf * w, dtype=torch.float32, device=self.device)
-        t0 = 0
-        for i in range(F):
-            first = 1 if self._fresh else 0
-            torch.ops.sf_hip.vae_decode_frame(self._handle, state, scratch, z[i], out[t0:], h, w, self._nframes)
-            self._nframes += 1
-            t0 += 1 if first else tf
+        t0 = i = 0
+        while i < F:
+            # the frame that follows a reset is decoded alone (one output frame); after it, groups of up to
+            # frames_per_call latent frames per C call -- bit-identical to one call per frame, but the low-resolution
+            # stages fill the chip and every launch has a shorter tail
+            g = 1 if self._fresh else min(self.frames_per_call, F - i)
+            if self._slot + g > self.window_frames:
+                window, history_at = 0, self._slot
+            else:
+                window = history_at = self._slot
+            torch.ops.sf_hip.vae_decode_frames(self._handle, state, scratch, z[i:i + g], out[t0:], h, w, self.window_frames,
+                                               self._nframes, window, history_at)
+            self._slot = window + g
+            self._nframes += g
+            t0 += 1 if self._fresh else tf * g
+            i += g
             self._fresh = False
         return out
 
@@ -197,7 +216,7 @@ class WanVAEWrapper(torch.nn.Module):
     (weights-only); FileNotFoundError when it is absent."""
 
     def __init__(self, state_dict: Optional[Dict[str, Tensor]] = None, device="cuda", shape: VaeShape = WAN_VAE,
-                 checkpoint_path: str = VAE_CHECKPOINT):
+                 checkpoint_path: str = VAE_CHECKPOINT, frames_per_call: int = 4):
         super().__init__()
         if state_dict is None:   # `WanVAEWrapper()` as the reference's pipelines construct it (wan_wrapper.py:72-76)
             import os
@@ -207,7 +226,7 @@ class WanVAEWrapper(torch.nn.Module):
             state_dict = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
         self.mean = torch.tensor(LATENT_MEAN, dtype=torch.float32)
         self.std = torch.tensor(LATENT_STD, dtype=torch.float32)
-        self.model = WanVAEDecoder(shape, state_dict, device)
+        self.model = WanVAEDecoder(shape, state_dict, device, frames_per_call=frames_per_call)
 
     def encode_to_latent(self, pixel: Tensor) -> Tensor:
         raise NotImplementedError("the VAE encoder (image-to-video conditioning, inference.py:145) is outside this path")

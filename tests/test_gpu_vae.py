@@ -253,6 +253,48 @@ def test_streaming_decode_equals_one_shot():
     assert torch.equal(torch.cat([c0, c1], 1), whole)
 
 
+@pytest.mark.parametrize("fpc", [2, 3, 4, 7])
+def test_grouped_frames_are_bit_identical_to_one_frame_per_call(fpc):
+    """sf_vae_decode_frames on groups of latent frames (what fills the chip at the low-resolution stages) against the
+    reference's iteration, one latent frame per call (vae.py:566-578): same bits, for whole clips, for ragged streaming
+    chunks, and across restarts of the sliding history windows."""
+    shape = vw.VAE_REDUCED
+    sd = vw.synth_vae_state_dict(shape, seed=5)
+    lat = torch.randn(1, 14, 16, 10, 6, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16).to(DEV)
+    one = sfa.WanVAEWrapper(sd, device=DEV, shape=shape, frames_per_call=1)
+    ref = one.decode_to_pixel(lat, use_cache=False)
+    assert ref.shape[1] == 1 + 4 * 13
+    vae = sfa.WanVAEWrapper(sd, device=DEV, shape=shape, frames_per_call=fpc)
+    assert torch.equal(vae.decode_to_pixel(lat, use_cache=False), ref)
+    # streaming: chunks of 3 latent frames (the first holds the frame that follows the reset), then a ragged tail
+    vae.model.clear_cache()
+    parts = [vae.decode_to_pixel(lat[:, a:b], use_cache=True) for a, b in ((0, 3), (3, 6), (6, 9), (9, 12), (12, 14))]
+    assert torch.equal(torch.cat(parts, 1), ref)
+    # one frame at a time through the grouped decoder, too (windows slide and restart every few calls)
+    vae.model.clear_cache()
+    parts = [vae.decode_to_pixel(lat[:, a:a + 1], use_cache=True) for a in range(14)]
+    assert torch.equal(torch.cat(parts, 1), ref)
+
+
+def test_decode_frames_rejects_bad_window_arguments():
+    shape = vw.VAE_REDUCED
+    vae = sfa.WanVAEWrapper(vw.synth_vae_state_dict(shape, seed=0), device=DEV, shape=shape, frames_per_call=2)
+    dec = vae.model
+    z = torch.zeros(3, 16, 8, 8, dtype=torch.bfloat16, device=DEV)
+    state, scratch = dec._buffers(8, 8)
+    out = torch.empty(12, 3, 64, 64, dtype=torch.float32, device=DEV)
+    K = dec.window_frames
+    op = torch.ops.sf_hip.vae_decode_frames
+    with pytest.raises(RuntimeError, match="decoded alone"):
+        op(dec._handle, state, scratch, z[:2], out, 8, 8, K, 0, 0, 0)            # the first chunk with a second frame
+    with pytest.raises(RuntimeError, match="n_frames"):
+        op(dec._handle, state, scratch, z, out, 8, 8, K, 1, 1, 1)                # 3 frames > window_frames - 1
+    with pytest.raises(RuntimeError, match="does not fit"):
+        op(dec._handle, state, scratch, z[:2], out, 8, 8, K, 2, 2, 2)            # slots 2, 3 of 3
+    with pytest.raises(RuntimeError, match="history_at"):
+        op(dec._handle, state, scratch, z[:1], out, 8, 8, K, 2, 1, 2)            # a restart must go to window 0
+
+
 def test_decode_matches_oracle_at_another_size_and_batch():
     shape = vw.VAE_REDUCED
     sd = vw.synth_vae_state_dict(shape, seed=3)

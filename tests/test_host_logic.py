@@ -382,7 +382,7 @@ def test_torch_custom_ops_are_registered_with_mutation_schemas():
     sch = {n: str(getattr(torch.ops.sf_hip, n).default._schema) for n in sfa.torch_ops.OPS}
     assert "Tensor(a5!)[] k_cache" in sch["dit_forward"] and "Tensor(a6!)[] v_cache" in sch["dit_forward"]
     assert "Tensor(a7!)[] ck_cache" in sch["dit_forward"] and "-> (Tensor, Tensor)" in sch["dit_forward"]
-    assert "Tensor(a1!) state" in sch["vae_decode_frame"] and "Tensor(a4!) out" in sch["vae_decode_frame"]
+    assert "Tensor(a1!) state" in sch["vae_decode_frames"] and "Tensor(a4!) out" in sch["vae_decode_frames"]
     assert "Tensor(a0!) out" in sch["gemm_out"] and "Tensor(a0!) out" in sch["lincomb_out"]
     assert "!" not in sch["attention"] and "!" not in sch["gemm"] and "!" not in sch["add_noise"]
 

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--lk", default="4680,18720,32760")
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--vae-frames", type=int, default=21)
+    ap.add_argument("--vae-fpc", default="4", help="latent frames per sf_vae_decode_frames call (comma list)")
     ap.add_argument("--batch", type=int, default=1, help="samples per attention launch")
     ap.add_argument("--structures", default="auto", help="GEMM tilings to time, e.g. auto,t128,pp256,pp128")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved timing rounds per (shape, structure); the best is printed")
@@ -50,7 +51,7 @@ def main():
     if "t5" in a.what:
         bench_t5(max(2, a.iters // 2))
     if "vae" in a.what:
-        bench_vae(a.vae_frames, max(1, a.iters // 5))
+        bench_vae(a.vae_frames, max(1, a.iters // 5), [int(x) for x in a.vae_fpc.split(",")])
     if "conv" in a.what:
         bench_conv(a.iters, a.rounds)
     if "gemm" in a.what:
@@ -107,17 +108,21 @@ def bench_conv(iters, rounds):
             print(f"conv3x3x3 Cin={cin} Cout={cout} T={T} {H}x{W} {st:5s}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
-def bench_vae(frames, iters):
+def bench_vae(frames, iters, fpcs=(4,)):
     import self_forcing_amd as sfa
     from self_forcing_amd import vae_weights as vw
     dev = "cuda:0"
-    vae = sfa.WanVAEWrapper(vw.synth_vae_state_dict(vw.WAN_VAE, seed=0), device=dev)
+    sd = vw.synth_vae_state_dict(vw.WAN_VAE, seed=0)
     lat = torch.randn(1, frames, 16, 60, 104, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(dev)
-    ms = timeit(lambda: vae.decode_to_pixel(lat), iters)
     fl = vw.vae_decode_flops(vw.WAN_VAE, 60, 104, frames)
     nf = 1 + 4 * (frames - 1)
-    print(f"vae decode {frames} latent frames -> {nf} frames 480x832: {ms:8.1f} ms  {nf / ms * 1e3:7.1f} frames/s  "
-          f"{fl / ms / 1e9:7.1f} TFLOP/s ({fl / 1e12:.1f} TFLOP)", flush=True)
+    for fpc in fpcs:
+        vae = sfa.WanVAEWrapper(sd, device=dev, frames_per_call=fpc)
+        ms = timeit(lambda: vae.decode_to_pixel(lat), iters)
+        print(f"vae decode {frames} latent frames -> {nf} frames 480x832, {fpc} latent frames per call: {ms:8.1f} ms  {nf / ms * 1e3:7.1f} frames/s  "
+              f"{fl / ms / 1e9:7.1f} TFLOP/s ({fl / 1e12:.1f} TFLOP)", flush=True)
+        del vae
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
