@@ -67,7 +67,10 @@ typedef struct sf_gemm_args {
 
 enum sf_gemm_structure { SF_GEMM_AUTO = 0, SF_GEMM_T128 = 1 /* 128 x 128 tile, 4 waves, 2 workgroups / CU */,
                          SF_GEMM_PP256 = 2 /* 256 x 256 tile, 8 waves, the two waves of a SIMD half a phase apart */,
-                         SF_GEMM_PP128 = 3 /* 128 x 256 tile, same structure, two phases per k-tile, 3-deep rings */ };
+                         SF_GEMM_PP128 = 3 /* 128 x 256 tile, same structure, two phases per k-tile, 3-deep rings */,
+                         SF_GEMM_PP224 = 4, SF_GEMM_PP192 = 5 /* the 256 x 256 kernel with 7 / 6 row tiles per wave: 224- and
+                                                                 192-row tiles for shapes whose 256-row tiles leave a round of
+                                                                 workgroups mostly empty */ };
 
 int sf_gemm_bf16(const sf_gemm_args* args, void* stream);
 

@@ -24,7 +24,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 # enum sf_attn_structure / sf_gemm_structure
 ATTN_STRUCTURES = {"auto": 0, "r64": 1, "w8": 2, "w4": 3}
 CONV_STRUCTURES = {"auto": 0, "igemm": 1, "halo": 2}
-GEMM_STRUCTURES = {"auto": 0, "t128": 1, "pp256": 2, "pp128": 3}
+GEMM_STRUCTURES = {"auto": 0, "t128": 1, "pp256": 2, "pp128": 3, "pp224": 4, "pp192": 5}
 
 
 class GemmArgs(C.Structure):

@@ -13,6 +13,7 @@
 // bank-conflict free.  The MFMA is issued as D = W_frag x X_frag (operands swapped) so that each
 // lane ends up with 4 CONSECUTIVE output columns of one row: 8-byte bf16x4 stores/loads in the
 // epilogue instead of 2-byte scattered ones.
+#include <type_traits>
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
 
@@ -162,6 +163,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x4 (&acc)[M
     bf16x4 rv[MB][4], ge[MB][4];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
+      if (m0 + i >= MT) break;
       const int m = min(m_base + (m0 + i) * 16 + r16, p.M - 1);
       const bf16_t* e0row = GATE ? p.gate_e0 + (long)(m / p.rows_per_group) * p.gate_group_stride : nullptr;
 #pragma unroll
@@ -172,6 +174,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmP& p, f32x4 (&acc)[M
     }
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
+      if (m0 + i >= MT) break;
       const int row = (m0 + i) * 16 + r16;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -339,20 +342,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
 // the barrier behind the vmcnt(4) of phase (t, 3), executed by every wave: everything but B(t+2) has landed.
 constexpr int PP_THREADS = 512;
 
-template <int MT>   // M tiles of 16 rows per wave: 8 (256-row workgroup tile) or 4 (128-row)
+template <int MT>   // M tiles of 16 rows per wave: 8 (256-row workgroup tile), 7 (224), 6 (192)
 struct PPCfg {
   static constexpr int BM = 32 * MT;
   static constexpr int A_BYTES = BM * 128;          // one k-tile of A: BM rows x 64 bf16
   static constexpr int B_BYTES = 256 * 128;
   static constexpr int STAGE = A_BYTES + B_BYTES;
-  static constexpr int LDS = 2 * STAGE;             // 128 KiB (MT = 8) / 96 KiB (MT = 4)
-  static constexpr int PA = MT / 4;                 // LDS-DMA pieces (8 rows x 128 B) per wave per A half-tile
+  static constexpr int LDS = 2 * STAGE;             // 128 KiB (MT = 8)
+  static constexpr int PA = (2 * MT + 7) / 8;       // LDS-DMA pieces (8 rows x 128 B) per wave per A half-tile (2 MT pieces over 8 waves)
 };
 
 template <int EPI, int MT>
 __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
   using Cfg = PPCfg<MT>;
-  constexpr int BMp = Cfg::BM, PA = Cfg::PA, HQ = MT / 2;
+  constexpr int BMp = Cfg::BM, PA = Cfg::PA;
+  constexpr int HQA = (MT + 1) / 2, HQB = MT / 2;    // row tiles of the wave's two "quarters" (4 + 3 at MT = 7)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  constexpr int GROUP_M = MT == 8 ? 4 : 8;
+  constexpr int GROUP_M = MT >= 6 ? 4 : 8;
   const int width = GROUP_M * p.tiles_n;
   const int group = wg / width, first_m = group * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
@@ -392,7 +396,8 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
   auto dma_a = [&](int h, int kt) {
     char* base = smem + (kt & 1) * Cfg::STAGE + h * (Cfg::A_BYTES / 2) + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) glds16(a_src[h][i] + kt * BK, base + i * 8192);
+    for (int i = 0; i < PA; ++i)
+      if (wave + 8 * i < 2 * MT) glds16(a_src[h][i] + kt * BK, base + i * 8192);   // (wave-uniform; the youngest requests of a k-tile are B's either way)
   };
   auto dma_b = [&](int h, int kt) {
     char* base = smem + (kt & 1) * Cfg::STAGE + Cfg::A_BYTES + h * (Cfg::B_BYTES / 2) + wave * 1024;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[HQ][2], bfr[4][2];
+  bf16x8 af[HQA][2], bfr[4][2];
 
 #ifdef SF_STAMP   // diagnostic build (tools/probes/gemm_stamp.py): where a tile's time goes; stamps go to a buffer of their own
   unsigned long long* stamp = (EPI == SF_EPI_BIAS && p.gate_e0) ? reinterpret_cast<unsigned long long*>(const_cast<bf16_t*>(p.gate_e0)) + ((long)bid * 2 + grp) * 8 : nullptr;
@@ -435,26 +440,28 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto cluster = [&](int q, int c0) {               // MT/2 row tiles x 2 column tiles x 2 sub-steps of 32
+  auto cluster = [&](auto qc, int c0) {             // one quarter: HQA / HQB row tiles x 2 column tiles x 2 sub-steps of 32
+    constexpr int q = decltype(qc)::value, NQ = q == 0 ? HQA : HQB;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int mt = 0; mt < HQ; ++mt)
+      for (int mt = 0; mt < NQ; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-          acc[q * HQ + mt][c0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c0 + nt][ks], af[mt][ks], acc[q * HQ + mt][c0 + nt], 0, 0, 0);
+          acc[q * HQA + mt][c0 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[c0 + nt][ks], af[mt][ks], acc[q * HQA + mt][c0 + nt], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto read_a = [&](const char* buf, int q) {
+  auto read_a = [&](const char* buf, auto qc) {
+    constexpr int q = decltype(qc)::value, NQ = q == 0 ? HQA : HQB;
 #pragma unroll
-    for (int mt = 0; mt < HQ; ++mt)
+    for (int mt = 0; mt < NQ; ++mt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        af[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + (q * HQ + mt) * 2048 + coff[ks]);
+        af[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + x_row_off + (q * HQA + mt) * 2048 + coff[ks]);
   };
   auto read_b = [&](const char* buf, int c0) {
 #pragma unroll
@@ -464,25 +471,27 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
         bfr[c0 + nt][ks] = *reinterpret_cast<const bf16x8*>(buf + w_row_off + (c0 + nt) * 2048 + coff[ks]);
   };
 
+  constexpr std::integral_constant<int, 0> Q0{};
+  constexpr std::integral_constant<int, 1> Q1{};
   for (int kt = 0; kt < nk; ++kt) {
     const char* buf = smem + (kt & 1) * Cfg::STAGE;
     const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
     // phase 0
-    read_a(buf, 0);
+    read_a(buf, Q0);
     read_b(buf, 0);
     if (more1) dma_a(0, kt + 1);
     end_load_segment();
-    cluster(0, 0);
+    cluster(Q0, 0);
     // phase 1
     read_b(buf, 2);
     if (more1) dma_a(1, kt + 1);
     end_load_segment();
-    cluster(0, 2);
+    cluster(Q0, 2);
     // phase 2
-    read_a(buf, 1);
+    read_a(buf, Q1);
     if (more2) dma_b(0, kt + 2);
     end_load_segment();
-    cluster(1, 2);
+    cluster(Q1, 2);
     // phase 3: everything but the two half-tiles of B(kt + 2) must have landed before the next tile's first reads
     if (more2) {
       dma_b(1, kt + 2);
@@ -491,7 +500,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_pp_kernel(GemmP p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     end_load_segment();
-    cluster(1, 0);
+    cluster(Q1, 0);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with the extra barrier of the second group: all clusters done
 #ifdef SF_STAMP
@@ -723,25 +732,34 @@ extern "C" int sf_gemm_bf16(const sf_gemm_args* a, void* stream) {
   p.tiles_n = (a->N + BN - 1) / BN;
   hipStream_t s = (hipStream_t)stream;
   p.tiles_m = (a->M + BM - 1) / BM;
-  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_PP128, "sf_gemm_bf16: unknown structure %d", a->structure);
+  SF_CHECK(a->structure >= SF_GEMM_AUTO && a->structure <= SF_GEMM_PP192, "sf_gemm_bf16: unknown structure %d", a->structure);
   {
     int st = a->structure;
     const bool pp_ok = a->batch <= 1 && a->epilogue != SF_EPI_F32 && a->K >= 2 * BK;
     if (st == SF_GEMM_AUTO) {
-      // Large problems take the ping-pong structure; its row tile (256 or 128) is the one whose tile count wastes less
-      // of the chip's 256 workgroup slots (one workgroup per CU).  Everything else: 128 x 128 tiles, two per CU.
+      // Large problems take the ping-pong structure with the row tile (256 / 224 / 192 / 128 rows x 256 columns, one
+      // workgroup per CU) that needs the least time for its ROUNDS of 256 workgroups: rounds x (a tile's k-loop, which
+      // scales with its rows, slightly worse for the smaller register tiles, + a fixed prologue share).  Everything
+      // else: 128 x 128 tiles, two per CU.
       st = SF_GEMM_T128;
       if (pp_ok && a->M >= 1024 && a->N >= 1024 && a->K >= 512) {
+        static const struct { int st, rows; double rel; } cand[] = {
+            {SF_GEMM_PP256, 256, 1.00}, {SF_GEMM_PP224, 224, 1.02}, {SF_GEMM_PP192, 192, 1.05}, {SF_GEMM_PP128, 128, 1.14}};
         const long tn = (a->N + 255) / 256;
-        const long t256 = (long)((a->M + 255) / 256) * tn, t128 = (long)((a->M + 127) / 128) * tn;
-        const double e256 = (double)a->M * a->N / (((t256 + 255) / 256) * 256.0 * 256 * 256);
-        const double e128 = (double)a->M * a->N / (((t128 + 255) / 256) * 256.0 * 128 * 256) * 0.88;   // smaller register tile: k-loop 1240-1300 vs 1450-1500 TFLOP/s
-        st = e256 >= e128 ? SF_GEMM_PP256 : SF_GEMM_PP128;
+        double best = 1e30;
+        for (const auto& c : cand) {
+          const long tiles = (long)((a->M + c.rows - 1) / c.rows) * tn;
+          const double cost = (double)((tiles + 255) / 256) * (c.rows / 256.0 * c.rel + 0.04);
+          if (cost < best - 1e-9) { best = cost; st = c.st; }
+        }
       }
     }
-    if ((st == SF_GEMM_PP256 || st == SF_GEMM_PP128) && !pp_ok) st = SF_GEMM_T128;
-    if (st == SF_GEMM_PP256 || st == SF_GEMM_PP128) {
-      const int rc = st == SF_GEMM_PP256 ? launch_pp_epi<8>(p, a->epilogue, s) : launch_pp2_epi(p, a->epilogue, s);
+    const bool is_pp = st == SF_GEMM_PP256 || st == SF_GEMM_PP224 || st == SF_GEMM_PP192 || st == SF_GEMM_PP128;
+    if (is_pp && !pp_ok) st = SF_GEMM_T128;
+    else if (is_pp) {
+      const int rc = st == SF_GEMM_PP256 ? launch_pp_epi<8>(p, a->epilogue, s)
+                   : st == SF_GEMM_PP224 ? launch_pp_epi<7>(p, a->epilogue, s)
+                   : st == SF_GEMM_PP192 ? launch_pp_epi<6>(p, a->epilogue, s) : launch_pp2_epi(p, a->epilogue, s);
       SF_CHECK(rc == 0, "sf_gemm_bf16: unknown epilogue %d", a->epilogue);
       SF_HIP_LAUNCH_CHECK("sf_gemm_bf16");
       return 0;

@@ -59,7 +59,7 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, epilogue: str = "b
          resid: Optional[Tensor] = None, gate_mod: Optional[Tensor] = None, gate_e0: Optional[Tensor] = None,
          rows_per_group: int = 1, out: Optional[Tensor] = None, structure: str = "auto") -> Tensor:
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  gate_e0: [groups, N] view (row stride free).
-    `structure` ("auto" | "t128" | "pp256" | "pp128") forces a tiling (tests / A-B timing)."""
+    `structure` ("auto" | "t128" | "pp256" | "pp224" | "pp192" | "pp128") forces a tiling (tests / A-B timing)."""
     a, w = _rows(a, "a"), _rows(w, "w")
     epi, st = _EPI[epilogue], _lib.GEMM_STRUCTURES[structure]
     if out is None:

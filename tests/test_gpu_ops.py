@@ -132,7 +132,7 @@ def test_gemm_large_tile_structure(epi):
     assert rel(out, ref) < 4e-3
 
 
-@pytest.mark.parametrize("structure", ["t128", "pp256", "pp128"])
+@pytest.mark.parametrize("structure", ["t128", "pp256", "pp224", "pp192", "pp128"])
 @pytest.mark.parametrize("M,N,K,epi", [(4680, 1536, 1536, "gate_resid"), (4680, 4608, 1536, "bias"), (1560, 8960, 1536, "gelu"),
                                        (4680, 1536, 8960, "gate_resid"), (10800, 5120, 5120, "resid"), (1100, 1288, 128, "gelu"),
                                        (257, 264, 192, "resid"), (3000, 1024, 64, "bias"), (9360, 8960, 512, "gelu"), (9360, 4608, 1536, "bias")])
@@ -173,7 +173,7 @@ def test_gemm_pingpong_is_race_free_under_repetition():
     side = torch.cuda.Stream()
     junk = torch.empty(64 << 20, dtype=torch.bfloat16, device=DEV)
     for (M, N, K, st) in [(4680, 1536, 8960, "pp128"), (4680, 8960, 1536, "pp256"), (4680, 4608, 1536, "pp128"), (2048, 2048, 2048, "pp256"),
-                          (9360, 8960, 1536, "pp256"), (9360, 1536, 8960, "pp256")]:
+                          (9360, 8960, 1536, "pp224"), (9360, 1536, 8960, "pp224"), (4680, 4608, 1536, "pp192"), (9360, 4608, 1536, "pp224")]:
         a, w = bf((M, K), g).to(DEV), bf((N, K), g, 1.0 / K ** 0.5).to(DEV)
         first = ops.gemm(a, w, None, structure=st)
         assert rel(first, a.float().cpu() @ w.float().cpu().t()) < 4e-3

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--vae-frames", type=int, default=21)
     ap.add_argument("--vae-fpc", default="4", help="latent frames per sf_vae_decode_frames call (comma list)")
     ap.add_argument("--batch", type=int, default=1, help="samples per attention launch")
-    ap.add_argument("--structures", default="auto", help="GEMM tilings to time, e.g. auto,t128,pp256,pp128")
+    ap.add_argument("--structures", default="auto", help="GEMM tilings to time, e.g. auto,t128,pp256,pp224,pp192,pp128")
     ap.add_argument("--rounds", type=int, default=1, help="interleaved timing rounds per (shape, structure); the best is printed")
     a = ap.parse_args()
     dev = "cuda:0"

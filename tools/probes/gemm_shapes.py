@@ -1,6 +1,6 @@
 """Separates a GEMM structure's per-tile FIXED cost (workgroup start, prologue, epilogue) from its k-loop rate: the same
 (M, N) at two K values, interleaved rounds in one process, best of each.
-    python tools/probes/gemm_shapes.py [structures, default t128,pp256,pp128]"""
+    python tools/probes/gemm_shapes.py [structures, default t128,pp256,pp224,pp192,pp128]"""
 import os
 import sys
 
@@ -22,7 +22,7 @@ def t(fn, it=20):
     return e0.elapsed_time(e1) / it
 
 
-structures = (sys.argv[1] if len(sys.argv) > 1 else "t128,pp256,pp128").split(",")
+structures = (sys.argv[1] if len(sys.argv) > 1 else "t128,pp256,pp224,pp192,pp128").split(",")
 g = torch.Generator().manual_seed(0)
 K1, K2 = 1536, 6144
 for (M, N, epi) in [(4680, 8960, "gelu"), (4680, 8960, "bias"), (4680, 4608, "bias"), (4680, 1536, "resid"), (4096, 4096, "bias"),
