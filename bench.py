@@ -86,18 +86,6 @@ def rollout_flops(shape, frames, nfpb, n_steps, fs, window_frames=0, executed=Fa
     return total
 
 
-def time_kernel(fn, iters):
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()          # recorded on torch's current stream = the stream the C-ABI launches on
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters  # ms
-
-
 def time_graph(fn, iters):
     """Mean device time of `fn`'s kernels with the launches replayed from a HIP graph: for kernels of a few
     microseconds the Python call (allocation + dispatcher + ctypes) takes longer than the kernel, and timing eager
@@ -124,8 +112,9 @@ def time_graph(fn, iters):
 
 def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
     """Average launch duration of the self-attention kernel over the Lk values one rollout visits
-    (each chunk index launches it equally often), and of the biggest GEMM, from events on the
-    launch stream."""
+    (each chunk index launches it equally often), and of the biggest GEMM: HIP events around launches
+    replayed from a HIP graph on the launch stream (back-to-back device time, which is what rocprofv3's
+    per-kernel average shows; eager launches through the operator layer leave gaps between kernels)."""
     H = shape.num_heads
     n = nfpb * fs
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -136,7 +125,7 @@ def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
     durs, flops = [], []
     for chunk in range(frames // nfpb):
         lk = min((chunk + 1) * n, lk_max)
-        ms = time_kernel(lambda: ops.attention(q, k[:, :lk], v[:, :lk]), 10)
+        ms = time_graph(lambda: ops.attention(q, k[:, :lk], v[:, :lk]), 10)
         durs.append(ms)
         flops.append(4.0 * shape.dim * n * lk)
     avg_ms = sum(durs) / len(durs)
@@ -164,11 +153,11 @@ def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
     w1 = (torch.randn(shape.ffn_dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
     b1 = torch.zeros(shape.ffn_dim, dtype=torch.bfloat16, device=dev)
     hbuf = torch.empty(n, shape.ffn_dim, dtype=torch.bfloat16, device=dev)
-    ms1 = time_kernel(lambda: ops.gemm(a, w1, b1, epilogue="gelu", out=hbuf), 20)
+    ms1 = time_graph(lambda: ops.gemm(a, w1, b1, epilogue="gelu", out=hbuf), 20)
     w2 = (torch.randn(shape.dim, shape.ffn_dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
     b2 = torch.zeros(shape.dim, dtype=torch.bfloat16, device=dev)
     o2 = torch.empty(n, shape.dim, dtype=torch.bfloat16, device=dev)
-    ms2 = time_kernel(lambda: ops.gemm(hbuf, w2, b2, out=o2), 20)
+    ms2 = time_graph(lambda: ops.gemm(hbuf, w2, b2, out=o2), 20)
     fl = 2.0 * n * shape.dim * shape.ffn_dim
     gemm = {"ffn0_tflops": fl / (ms1 * 1e-3) / 1e12, "ffn2_tflops": fl / (ms2 * 1e-3) / 1e12,
             "ffn0_ms": ms1, "ffn2_ms": ms2, "M": n, "C": shape.dim, "ffn": shape.ffn_dim}

@@ -49,44 +49,76 @@ __device__ __forceinline__ void ln_stats(const float (&v)[NCH][8], int C, float 
   rstd = rsqrtf(wave_sum(q) / (float)C + eps);
 }
 
-// MODE 0: modulate (shift/scale = mod + e0[group]); MODE 1: affine weight/bias
+// MODE 0: modulate (shift/scale = mod + e0[group]); MODE 1: affine weight/bias.
+// One wave per workgroup, LN_RPW consecutive rows per wave: the four (two) parameter vectors are as many bytes as four
+// (two) rows, so loading them once per ROW made the kernel's load path (64 B/clk/CU) move 3x the row's bytes (3.4 TB/s
+// of HBM traffic measured); here they are combined once per wave (again when a row starts a new modulation group) and
+// the rows' loads are all issued before the first statistic.
+#ifndef SF_LN_RPW
+#define SF_LN_RPW 2
+#endif
+template <int NCH> struct LnRows { static constexpr int value = NCH <= 4 ? SF_LN_RPW : (NCH <= 6 ? 2 : 1); };   // register budget: rows in flight
 template <int NCH, int MODE>
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
-                                                        int M, int C, float eps, const bf16_t* __restrict__ p0,
-                                                        const bf16_t* __restrict__ p1, const bf16_t* __restrict__ e0_shift,
-                                                        const bf16_t* __restrict__ e0_scale, long e0_group_stride,
-                                                        int rows_per_group) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= M) return;
-  float v[NCH][8];
-  load_row<NCH>(x + (long)row * C, lane, v);
-  float mean, rstd;
-  ln_stats<NCH>(v, C, eps, mean, rstd);
-  const long goff = (MODE == 0) ? (long)(row / rows_per_group) * e0_group_stride : 0;
+__global__ __launch_bounds__(64) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                       int M, int C, float eps, const bf16_t* __restrict__ p0,
+                                                       const bf16_t* __restrict__ p1, const bf16_t* __restrict__ e0_shift,
+                                                       const bf16_t* __restrict__ e0_scale, long e0_group_stride,
+                                                       int rows_per_group) {
+  constexpr int LN_RPW = LnRows<NCH>::value;
+  const int lane = threadIdx.x;
+  const int row0 = blockIdx.x * LN_RPW;
+  bf16x8 raw[LN_RPW][NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int e = (i * 64 + lane) * 8;
-    bf16x8 o;
-    if (MODE == 0) {
-      const bf16x8 ms = *reinterpret_cast<const bf16x8*>(p0 + e);       // modulation shift
-      const bf16x8 mc = *reinterpret_cast<const bf16x8*>(p1 + e);       // modulation scale
-      const bf16x8 es = *reinterpret_cast<const bf16x8*>(e0_shift + goff + e);
-      const bf16x8 ec = *reinterpret_cast<const bf16x8*>(e0_scale + goff + e);
+  for (int r = 0; r < LN_RPW; ++r) {
+    const long row = min(row0 + r, M - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // (modulation + e0) is a bf16 tensor in the reference (causal_model.py:310)
-        const float shift = (float)(bf16_t)((float)ms[j] + (float)es[j]);
-        const float scale = (float)(bf16_t)((float)mc[j] + (float)ec[j]);
-        o[j] = (bf16_t)((v[i][j] - mean) * rstd * (1.0f + scale) + shift);
+    for (int i = 0; i < NCH; ++i) raw[r][i] = *reinterpret_cast<const bf16x8*>(x + row * C + (i * 64 + lane) * 8);
+  }
+  bf16x8 scl[NCH], add[NCH];                // y = (x - mean) * rstd * (1 + scl) + add  (MODE 1: * scl + add); kept packed
+  int cur_group = -1;
+#pragma unroll
+  for (int r = 0; r < LN_RPW; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const int grp = MODE == 0 ? row / rows_per_group : 0;
+    if (grp != cur_group) {
+      cur_group = grp;
+      const long goff = (long)grp * e0_group_stride;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int e = (i * 64 + lane) * 8;
+        if (MODE == 0) {
+          const bf16x8 ms = *reinterpret_cast<const bf16x8*>(p0 + e);       // modulation shift
+          const bf16x8 mc = *reinterpret_cast<const bf16x8*>(p1 + e);       // modulation scale
+          const bf16x8 es = *reinterpret_cast<const bf16x8*>(e0_shift + goff + e);
+          const bf16x8 ec = *reinterpret_cast<const bf16x8*>(e0_scale + goff + e);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            // (modulation + e0) is a bf16 tensor in the reference (causal_model.py:310)
+            add[i][j] = (bf16_t)((float)ms[j] + (float)es[j]);
+            scl[i][j] = (bf16_t)((float)mc[j] + (float)ec[j]);
+          }
+        } else {
+          scl[i] = *reinterpret_cast<const bf16x8*>(p0 + e);
+          add[i] = *reinterpret_cast<const bf16x8*>(p1 + e);
+        }
       }
-    } else {
-      const bf16x8 w = *reinterpret_cast<const bf16x8*>(p0 + e);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(p1 + e);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((v[i][j] - mean) * rstd * (float)w[j] + (float)b[j]);
     }
-    *reinterpret_cast<bf16x8*>(out + (long)row * C + e) = o;
+    float v[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = (float)raw[r][i][j];
+    float mean, rstd;
+    ln_stats<NCH>(v, C, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        o[j] = (bf16_t)((v[i][j] - mean) * rstd * (MODE == 0 ? 1.0f + (float)scl[i][j] : (float)scl[i][j]) + (float)add[i][j]);
+      *reinterpret_cast<bf16x8*>(out + (long)row * C + (i * 64 + lane) * 8) = o;
+    }
   }
 }
 
@@ -344,10 +376,10 @@ __global__ __launch_bounds__(256) void sinusoid_kernel(const void* __restrict__ 
 template <int MODE>
 int launch_layernorm(const bf16_t* x, bf16_t* out, int M, int C, float eps, const bf16_t* p0, const bf16_t* p1,
                      const bf16_t* e0s, const bf16_t* e0c, long gs, int rpg, hipStream_t s) {
-  const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+  const dim3 block(64);
   switch (C / 512) {
 #define SF_LN_CASE(N) \
-  case N: hipLaunchKernelGGL((layernorm_kernel<N, MODE>), grid, block, 0, s, x, out, M, C, eps, p0, p1, e0s, e0c, gs, rpg); break;
+  case N: hipLaunchKernelGGL((layernorm_kernel<N, MODE>), dim3((M + LnRows<N>::value - 1) / LnRows<N>::value), block, 0, s, x, out, M, C, eps, p0, p1, e0s, e0c, gs, rpg); break;
     SF_LN_CASE(1) SF_LN_CASE(2) SF_LN_CASE(3) SF_LN_CASE(4) SF_LN_CASE(5) SF_LN_CASE(6) SF_LN_CASE(8) SF_LN_CASE(10)
 #undef SF_LN_CASE
     default: sf_set_error("layernorm: unsupported channel count %d", C); return -1;
