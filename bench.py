@@ -89,7 +89,9 @@ def rollout_flops(shape, frames, nfpb, n_steps, fs, window_frames=0, executed=Fa
 def time_graph(fn, iters):
     """Mean device time of `fn`'s kernels with the launches replayed from a HIP graph: for kernels of a few
     microseconds the Python call (allocation + dispatcher + ctypes) takes longer than the kernel, and timing eager
-    launches measures the host."""
+    launches measures the host.  The timed replays follow ~30 ms of the same replays WITHOUT a host synchronisation in
+    between: after an idle gap the chip needs milliseconds to raise its clocks again (tools/probes/sustained.py: the
+    ffn.0 GEMM takes 128-146 us right after 2 s of idle, 108-112 us under load), and a rollout never idles."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -100,14 +102,21 @@ def time_graph(fn, iters):
     with torch.cuda.graph(graph):
         for _ in range(iters):
             fn()
-    graph.replay()
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     graph.replay()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / iters
+    t1 = max(e0.elapsed_time(e1), 1e-3)                 # ms per replay (cold clocks: an upper bound)
+    n_warm, n_timed = max(1, int(30.0 / t1)), max(1, int(20.0 / t1))
+    for _ in range(n_warm):
+        graph.replay()
+    e0.record()
+    for _ in range(n_timed):
+        graph.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / (iters * n_timed)
 
 
 def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):

@@ -12,6 +12,6 @@ while [ $# -ge 2 ]; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize \
      -fno-honor-nans -fno-honor-infinities -DSF_R64_INC="\"/tmp/r64_$name.inc\"" -c attention.hip -o /tmp/abl_att_$name.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 gemm_bf16.o /tmp/abl_att_$name.o elementwise.o \
-     small_linear.o dit_forward.o conv_igemm.o vae_elementwise.o vae_decode.o t5_encoder.o capi.o -o "$ROOT/tools/probes/abl/libabl_$name.so"
+     small_linear.o dit_forward.o conv_igemm.o conv_halo.o vae_elementwise.o vae_decode.o t5_encoder.o capi.o -o "$ROOT/tools/probes/abl/libabl_$name.so"
   echo built $name
 done
