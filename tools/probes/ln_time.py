@@ -32,3 +32,11 @@ for (M, C, groups) in [(4680, 1536, 3), (9360, 1536, 6), (10800, 5120, 3), (4680
     us2 = replay(lambda: ops.layernorm_affine(x, w, b))
     by = 2.0 * M * C * 2
     print(f"M={M} C={C}: modulate {us:6.2f} us {by / us / 1e6:5.2f} TB/s | affine {us2:6.2f} us {by / us2 / 1e6:5.2f} TB/s", flush=True)
+
+# the time projection (M = frames per chunk = 3, K = C, N = 6 C): weights streamed once
+for (C,) in [(1536,), (5120,)]:
+    xs = torch.randn(3, C).to(torch.bfloat16).cuda()
+    w6 = (torch.randn(6 * C, C) * 0.02).to(torch.bfloat16).cuda()
+    b6 = torch.zeros(6 * C, dtype=torch.bfloat16, device="cuda")
+    us = replay(lambda: ops.small_linear(xs, w6, b6, act_in="silu"))
+    print(f"small_linear M=3 K={C} N={6 * C}: {us:6.2f} us {6.0 * C * C * 2 / us / 1e6:5.2f} TB/s of weights", flush=True)
