@@ -162,6 +162,28 @@ int check_model(const sf_vae_model* m, int h, int w, int K) {
   return 0;
 }
 
+// every cached convolution's input volume: fn(buffer, frames per latent frame at its stage, bytes per frame, is it a
+// time convolution's volume)
+template <typename Fn>
+int for_each_volume(const sf_vae_model* m, const Plan& p, int h, int w, Fn fn) {
+  const int C0 = m->conv1.cout, L = m->n_stages - 1;
+  int rc = fn(p.c1_in, 1, vol(1, h, w, m->conv1.cin), false);
+  if (rc) return rc;
+  char* mids[4] = {p.mid0.a1, p.mid0.a2, p.mid2.a1, p.mid2.a2};
+  for (char* b : mids)
+    if ((rc = fn(b, 1, vol(1, h, w, C0), false)) != 0) return rc;
+  for (int i = 0; i < m->n_stages; ++i) {
+    for (int j = 0; j < m->res_per_stage; ++j) {
+      const sf_vae_resblock& r = res_at(m, i, j);
+      const BlockBufs& b = p.blk[i * m->res_per_stage + j];
+      if ((rc = fn(b.a1, p.Tmax[i], vol(1, p.H[i], p.W[i], r.conv1.cin), false)) != 0) return rc;
+      if ((rc = fn(b.a2, p.Tmax[i], vol(1, p.H[i], p.W[i], r.conv2.cin), false)) != 0) return rc;
+    }
+    if (p.tc[i] && (rc = fn(p.tc[i], p.Tmax[i], vol(1, p.H[i], p.W[i], m->time_conv[i].cin), true)) != 0) return rc;
+  }
+  return fn(p.head_in, p.Tmax[L], vol(1, p.H[L], p.W[L], m->head_conv.cin), false);
+}
+
 #define SF_TRY(expr)            \
   do {                          \
     int rc__ = (expr);          \
@@ -256,11 +278,17 @@ extern "C" size_t sf_vae_scratch_bytes(const sf_vae_model* m, int h, int w, int 
 
 extern "C" int sf_vae_reset(const sf_vae_model* m, void* state, size_t state_bytes, int h, int w, int window_frames, void* stream) {
   SF_TRY(check_model(m, h, w, window_frames));
-  const Plan p = make_plan(m, nullptr, nullptr, h, w, window_frames);
+  const Plan p = make_plan(m, state, nullptr, h, w, window_frames);
   SF_CHECK(state && state_bytes >= p.state_total, "sf_vae_reset: state too small (%zu < %zu)", state_bytes, p.state_total);
-  hipError_t e = hipMemsetAsync(state, 0, p.state_total, (hipStream_t)stream);
-  SF_CHECK(e == hipSuccess, "sf_vae_reset: memset failed: %s", hipGetErrorString(e));
-  return 0;
+  // Only the two history frames at the front of every volume are ever read before they are written (the first window
+  // after a reset starts at slot 0; its new frames, and every later window's, are written by their producer first):
+  // zeroing them -- 2 of 2 + K T frames -- is WanVAE_.clear_cache; the whole state would be ~20 GB of stores per clip.
+  hipStream_t s = (hipStream_t)stream;
+  return for_each_volume(m, p, h, w, [&](char* buf, int, size_t frame_bytes, bool) -> int {
+    hipError_t e = hipMemsetAsync(buf, 0, 2 * frame_bytes, s);
+    SF_CHECK(e == hipSuccess, "sf_vae_reset: memset failed: %s", hipGetErrorString(e));
+    return 0;
+  });
 }
 
 extern "C" int sf_vae_decode_frames(const sf_vae_model* m, void* state, size_t state_bytes, void* scratch, size_t scratch_bytes,
@@ -286,21 +314,8 @@ extern "C" int sf_vae_decode_frames(const sf_vae_model* m, void* state, size_t s
   const int Ch = m->head_conv.cin;
 
   // a restarted window: every volume's two history frames move to the front BEFORE any producer writes new frames
-  if (history_at != window) {
-    SF_TRY(place_history(cl, p.c1_in, 1, vol(1, h, w, m->conv1.cin)));
-    SF_TRY(place_history(cl, p.mid0.a1, 1, vol(1, h, w, C0))); SF_TRY(place_history(cl, p.mid0.a2, 1, vol(1, h, w, C0)));
-    SF_TRY(place_history(cl, p.mid2.a1, 1, vol(1, h, w, C0))); SF_TRY(place_history(cl, p.mid2.a2, 1, vol(1, h, w, C0)));
-    for (int i = 0; i < m->n_stages; ++i) {
-      for (int j = 0; j < m->res_per_stage; ++j) {
-        const sf_vae_resblock& r = res_at(m, i, j);
-        const BlockBufs& b = p.blk[i * m->res_per_stage + j];
-        SF_TRY(place_history(cl, b.a1, p.Tmax[i], vol(1, p.H[i], p.W[i], r.conv1.cin)));
-        SF_TRY(place_history(cl, b.a2, p.Tmax[i], vol(1, p.H[i], p.W[i], r.conv2.cin)));
-      }
-      if (p.tc[i]) SF_TRY(place_history(cl, p.tc[i], p.Tmax[i], vol(1, p.H[i], p.W[i], m->time_conv[i].cin), true));
-    }
-    SF_TRY(place_history(cl, p.head_in, p.Tmax[L], vol(1, p.H[L], p.W[L], Ch)));
-  }
+  if (history_at != window)
+    SF_TRY(for_each_volume(m, p, h, w, [&](char* buf, int Tmax, size_t frame_bytes, bool tc) { return place_history(cl, buf, Tmax, frame_bytes, tc); }));
 
   // un-scale + conv2 (1x1x1) -> the new frames of decoder.conv1's input volume; conv1 (vae.py:425-438)
   const size_t f_in = vol(1, h, w, m->conv1.cin);
