@@ -51,6 +51,58 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+class BoardSampler:
+    """Socket power and reported shader clock of this rank's GPU during the timed region, sampled from `rocm-smi` in a
+    background thread (one subprocess call per ~0.5 s: host-side only).  Reported beside the rates because the MFMA
+    kernels of this path run at the board's power limit; None when rocm-smi is unavailable."""
+
+    def __init__(self, device_index, period=0.5):
+        import re
+        import subprocess
+        import threading
+        self._re_clk = re.compile(r"sclk clock level[^\n]*\((\d+)Mhz\)")
+        self._re_pw = re.compile(r"(?:Average|Current Socket) Graphics Package Power \(W\): ([0-9.]+)")
+        self._sp, self._stop, self.samples = subprocess, False, []
+        self._cmd = ["rocm-smi", "--showclocks", "--showpower", "-d", str(device_index)]
+        self._period = period
+        self.limit_w = None
+        try:
+            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)",
+                            subprocess.run(["rocm-smi", "--showmaxpower", "-d", str(device_index)], capture_output=True, text=True, timeout=5).stdout)
+            self.limit_w = float(cap.group(1)) if cap else None
+        except Exception:   # noqa: BLE001
+            pass
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop:
+            try:
+                out = self._sp.run(self._cmd, capture_output=True, text=True, timeout=5).stdout
+            except Exception:   # noqa: BLE001  (no rocm-smi on this box: report nothing)
+                return
+            c, w = self._re_clk.search(out), self._re_pw.search(out)
+            if c and w:
+                self.samples.append((int(c.group(1)), float(w.group(1))))
+            time.sleep(self._period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._th.join(timeout=10)
+
+    def summary(self):
+        if len(self.samples) < 3:
+            return None
+        clk, pw = sorted(c for c, _ in self.samples), sorted(w for _, w in self.samples)
+        return {"samples": len(self.samples), "socket_power_w_median": pw[len(pw) // 2], "socket_power_w_max": pw[-1],
+                "sclk_reported_mhz_median": clk[len(clk) // 2], "socket_power_limit_w": self.limit_w,
+                "note": "rocm-smi during the timed region (every ~0.5 s; the limit from --showmaxpower); in-kernel cycle counters "
+                        "see 1.5-1.7 GHz of effective clock under this load (DESIGN.md section 4)"}
+
+
 def usable_cores():
     """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -334,6 +386,9 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    board = BoardSampler(local_rank) if rank == 0 else None
+    if board is not None:
+        board.__enter__()
     t0 = time.perf_counter()
     lats = pool.run(list(range(a.warmup, total)), one_step)
     torch.cuda.synchronize()
@@ -341,6 +396,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if board is not None:
+        board.__exit__()
     log(f"timed {a.steps} steps in {elapsed:.2f} s")
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -388,6 +445,8 @@ def main():
         "flop_note": "algorithmic = the reference's (n_steps + 1) full forwards per chunk (SURVEY 8d); executed = minus what the "
                      "context passes skip behind the last layer's K/V write (cache_only); achieved / frac divide EXECUTED work",
     }
+    if board is not None and board.summary() is not None:
+        out["board"] = board.summary()
     if one is not None:
         out["value_one_stream"] = decoded / one
         out["ms_per_rollout_one_stream"] = 1e3 * one
