@@ -412,3 +412,17 @@ def test_14b_720p_forward_vs_oracle():
     for f in range(F):     # frame by frame (the last frame ends in the ragged tiles)
         assert rel(f1[:, f], r1[:, f]) < 2e-2, f
     assert rel(pipe.kv_cache1[1]["k"], kv[1]["k"]) < 2e-2 and rel(pipe.kv_cache1[1]["v"], kv[1]["v"]) < 2e-2
+
+
+def test_vae_decode_full_size_grouping_is_bit_identical():
+    """The real decoder shape at 480 x 832: five latent frames decoded one per C call (every 384-channel convolution of
+    the 60 x 104 stages runs 112 workgroups of the 96-column tile) and in groups of four (the 192-column tile, fuller
+    rounds at every stage) give the same pixels to the last bit -- the claim behind `frames_per_call`."""
+    from self_forcing_amd import vae_weights as vw
+    sd = vw.synth_vae_state_dict(vw.WAN_VAE, seed=0)
+    lat = torch.randn(1, 5, 16, 60, 104, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(DEV)
+    one = sfa.WanVAEWrapper(sd, device=DEV, frames_per_call=1).decode_to_pixel(lat)
+    assert one.shape == (1, 17, 3, 480, 832) and torch.isfinite(one).all() and float(one.abs().max()) <= 1.0
+    torch.cuda.empty_cache()
+    four = sfa.WanVAEWrapper(sd, device=DEV, frames_per_call=4).decode_to_pixel(lat)
+    assert torch.equal(one, four)
