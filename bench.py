@@ -8,15 +8,20 @@ One "step" = one full rollout call `CausalInferencePipeline.inference` on `--bat
 such calls in flight, default 2; `value_one_stream` is ONE prompt alone on the GPU):
 Wan2.1-T2V-1.3B-shape random-init weights, 832x480 (latent 60x104), 21 latent = 81 decoded frames,
 3 frames per chunk, 4 warped denoising steps + 1 context pass per chunk = 35 DiT forwards,
-synthetic T5 embeddings resident in HBM (BASELINE.json configs[1], "S1").  With N > 1 (launched by
-torch.distributed.run, one process per GPU) every rank rolls out its own prompts
-(`rank, rank + N, ...`, the reference's DistributedSampler assignment, inference.py:96-100); RCCL
-carries only a weight-checksum all-reduce, barriers and the timing reduction -> weak scaling.
+synthetic T5 embeddings resident in HBM (BASELINE.json configs[1], "S1").  With N > 1 there is one process per GPU:
+either the caller started them (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), or -- when
+`--gpus N` is given and no torchrun environment is present -- this script starts them itself as child processes,
+before it makes any GPU call, and passes rank 0's JSON line through.  Every rank rolls out its own prompts
+(`rank, rank + N, ...`, the reference's DistributedSampler assignment, inference.py:96-100); RCCL carries only a
+weight-checksum all-reduce, barriers, the timing reduction and one gather of per-rank figures -> weak scaling
+(the protocol is `self_forcing_amd/distributed.py`, the code the world-size-2 gloo tests run; `--dist-selftest` runs
+it on CPU without any GPU work).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel (self-attention over the KV cache): algorithmic FLOPs per
-                  launch / its average launch duration, measured here with events on the launch
-                  stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  roofline     -- the dominant kernel (self-attention over the KV cache) AT THE BATCH THE TIMED REGION RUNS: algorithmic
+                  FLOPs per launch / its average launch duration, measured here with events on the launch stream,
+                  against the 2.5 PFLOP/s dense bf16 MFMA peak and against the peak MEASURED on this box
+                  (register-only MFMA loops under sustained clocks: `measured_peak`); the batch-1 figures beside it;
   cpu_baseline -- the CPU oracle (oracle/wan_oracle.py, bf16 mode = the reference's CPU path)
                   timed on this host's cores on a bounded sample (N = 1 only);
   vae_decode   -- SURVEY 8f-1, reported beside the metric (whose timed region is the DiT rollout,
@@ -171,88 +176,153 @@ def time_graph(fn, iters):
     return e0.elapsed_time(e1) / (iters * n_timed)
 
 
-def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0):
+def measured_peaks(dev):
+    """Ceilings measured on THIS box: register-only bf16 MFMA loops on all 256 CUs (random operands, one
+    wave per SIMD) and a 1 GiB streaming copy, both replayed from a HIP graph under sustained clocks."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    operands = torch.randn(4096, generator=g).to(torch.bfloat16).to(dev)
+    sink = torch.empty(256 * 256, dtype=torch.float32, device=dev)
+    out = {}
+    for shp in ("32x32x16", "16x16x32"):
+        fl = ops.probe_mfma(operands, sink, shape=shp, iters=2000)
+        ms = time_graph(lambda: ops.probe_mfma(operands, sink, shape=shp, iters=2000), 4)
+        out[f"mfma_{shp}_tflops"] = fl / (ms * 1e-3) / 1e12
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    ms = time_graph(lambda: ops.probe_copy(src, dst), 4)
+    out["hbm_copy_GBps"] = 2.0 * src.numel() / (ms * 1e-3) / 1e9
+    out["note"] = ("sf_probe_mfma: 256 workgroups x 4 waves, 4 independent accumulators, operands in registers, random bf16; "
+                   "sf_probe_copy: 1 GiB read + 1 GiB written, 16 B per lane; graph replays that follow ~30 ms of the same replays")
+    del src, dst
+    return out
+
+
+def committed_traffic(shape, n, lks, batch, window_frames):
+    """HBM bytes per attention launch from the newest committed rocprofv3 --pmc passes under profiles/ -- only when
+    they were taken at THIS shape (heads, queries, cache lengths, batch); else (None, why).  A counter run cannot share
+    a process with the timed one (profiled passes run at another clock), so the field is READ, and labelled."""
+    key = "attention_r64_kernel" if batch == 1 else f"attention_r64_kernel_batch{batch}"
+    want = {"heads": shape.num_heads, "queries": n, "lk": [int(x) for x in lks], "batch": batch}
+    if window_frames:
+        return None, "rolling-window run: no committed counter pass at these cache lengths"
+    for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                rec = json.load(f)[key]
+        except (OSError, KeyError, ValueError):
+            continue
+        have = rec.get("profiled_shape", {"heads": 12, "queries": 4680, "lk": [4680 * i for i in range(1, 8)], "batch": batch})
+        if have != want:
+            continue
+        val = rec.get("hbm_bytes_per_launch")
+        if val is None and "fetch_bytes_per_launch" in rec:     # (round-2 batch-2 record: fetch only; O is written once)
+            val = rec["fetch_bytes_per_launch"] + 2 * batch * n * shape.dim
+        return val, f"profiles/{cand} [{key}] (committed rocprofv3 --pmc pass at this shape, not measured in this run)"
+    return None, "no committed counter pass at this shape / batch"
+
+
+def roofline_leg(shape, dev, frames, nfpb, fs, window_frames=0, batch=1, peaks=None):
     """Average launch duration of the self-attention kernel over the Lk values one rollout visits
-    (each chunk index launches it equally often), and of the biggest GEMM: HIP events around launches
-    replayed from a HIP graph on the launch stream (back-to-back device time, which is what rocprofv3's
-    per-kernel average shows; eager launches through the operator layer leave gaps between kernels)."""
+    (each chunk index launches it equally often), and of the FFN GEMMs, at `batch` prompts per launch -- the kernels
+    the timed region runs -- and at batch 1: HIP events around launches replayed from a HIP graph on the launch stream
+    (back-to-back device time, which is what rocprofv3's per-kernel average shows; eager launches through the operator
+    layer leave gaps between kernels)."""
     H = shape.num_heads
     n = nfpb * fs
     g = torch.Generator(device="cpu").manual_seed(1)
-    q = torch.randn(1, n, H, 128, generator=g).to(torch.bfloat16).to(dev)
     lk_max = (min(frames, window_frames) if window_frames > 0 else frames) * fs
-    k = torch.randn(1, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
-    v = torch.randn(1, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
-    durs, flops = [], []
-    for chunk in range(frames // nfpb):
-        lk = min((chunk + 1) * n, lk_max)
-        ms = time_graph(lambda: ops.attention(q, k[:, :lk], v[:, :lk]), 10)
-        durs.append(ms)
-        flops.append(4.0 * shape.dim * n * lk)
-    avg_ms = sum(durs) / len(durs)
-    avg_flops = sum(flops) / len(flops)
-    traffic = traffic_src = None
-    for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), same shapes -- a counter
-            # run cannot share a process with the timed one (profiled passes run at another clock), so this field is
-            # READ from the newest committed pass and labelled with its file
-            with open(os.path.join(ROOT, "profiles", cand)) as f:
-                traffic = json.load(f)["attention_r64_kernel"]["hbm_bytes_per_launch"]
-            traffic_src = f"profiles/{cand} (committed rocprofv3 --pmc pass, not measured in this run)"
-            break
-        except (OSError, KeyError, ValueError):
-            pass
-    att = {"bound": "mfma", "kernel": "attention_r64_kernel (self-attention over the KV cache)",
-           "achieved": avg_flops / (avg_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": avg_flops / (avg_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "traffic": traffic,
-           "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the same 7 cache lengths)",
-           "traffic_source": traffic_src, "algorithmic_bytes_per_launch": 2 * (2 * n + 2 * sum(flops) / len(flops) / (4.0 * shape.dim * n)) * shape.dim,   # (Q + O + K + V) bf16
-           "avg_launch_ms": avg_ms, "flops_per_launch": avg_flops,
-           "per_lk_tflops": {str(min((i + 1) * n, lk_max)): flops[i] / (durs[i] * 1e-3) / 1e12 for i in range(len(durs))}}
-    # GEMMs: ffn.0 (N = ffn_dim) and ffn.2 (K = ffn_dim) at M = n
-    a = torch.randn(n, shape.dim, generator=g).to(torch.bfloat16).to(dev)
-    w1 = (torch.randn(shape.ffn_dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
-    b1 = torch.zeros(shape.ffn_dim, dtype=torch.bfloat16, device=dev)
-    hbuf = torch.empty(n, shape.ffn_dim, dtype=torch.bfloat16, device=dev)
-    ms1 = time_graph(lambda: ops.gemm(a, w1, b1, epilogue="gelu", out=hbuf), 20)
-    w2 = (torch.randn(shape.dim, shape.ffn_dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
-    b2 = torch.zeros(shape.dim, dtype=torch.bfloat16, device=dev)
-    o2 = torch.empty(n, shape.dim, dtype=torch.bfloat16, device=dev)
-    ms2 = time_graph(lambda: ops.gemm(hbuf, w2, b2, out=o2), 20)
-    fl = 2.0 * n * shape.dim * shape.ffn_dim
-    gemm = {"ffn0_tflops": fl / (ms1 * 1e-3) / 1e12, "ffn2_tflops": fl / (ms2 * 1e-3) / 1e12,
-            "ffn0_ms": ms1, "ffn2_ms": ms2, "M": n, "C": shape.dim, "ffn": shape.ffn_dim}
+    lks = [min((c + 1) * n, lk_max) for c in range(frames // nfpb)]
+    meas_peak = max(peaks["mfma_32x32x16_tflops"], peaks["mfma_16x16x32_tflops"]) if peaks else None
+
+    def attention_at(B):
+        q = torch.randn(B, n, H, 128, generator=g).to(torch.bfloat16).to(dev)
+        k = torch.randn(B, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
+        v = torch.randn(B, lk_max, H, 128, generator=g).to(torch.bfloat16).to(dev)
+        durs = [time_graph(lambda: ops.attention(q, k[:, :lk], v[:, :lk]), 10) for lk in lks]
+        flops = [4.0 * shape.dim * n * lk * B for lk in lks]
+        avg_ms, avg_flops = sum(durs) / len(durs), sum(flops) / len(flops)
+        ach = avg_flops / (avg_ms * 1e-3) / 1e12
+        traffic, src = committed_traffic(shape, n, lks, B, window_frames)
+        rec = {"bound": "mfma", "kernel": "attention_r64_kernel (self-attention over the KV cache)", "batch": B,
+               "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+               "traffic": traffic,
+               "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, mean over the same cache lengths)",
+               "traffic_source": src,
+               "algorithmic_bytes_per_launch": 2 * B * (2 * n + 2 * sum(lks) / len(lks)) * shape.dim,   # (Q + O + K + V) bf16
+               "avg_launch_ms": avg_ms, "flops_per_launch": avg_flops,
+               "per_lk_tflops": {str(lk): f / (d * 1e-3) / 1e12 for lk, f, d in zip(lks, flops, durs)}}
+        if meas_peak:
+            rec["measured_peak"] = meas_peak
+            rec["frac_of_measured_peak"] = ach / meas_peak
+        return rec
+
+    def gemms_at(B):
+        M = B * n
+        a = torch.randn(M, shape.dim, generator=g).to(torch.bfloat16).to(dev)
+        w1 = (torch.randn(shape.ffn_dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+        b1 = torch.zeros(shape.ffn_dim, dtype=torch.bfloat16, device=dev)
+        hbuf = torch.empty(M, shape.ffn_dim, dtype=torch.bfloat16, device=dev)
+        ms1 = time_graph(lambda: ops.gemm(a, w1, b1, epilogue="gelu", out=hbuf), 20)
+        w2 = (torch.randn(shape.dim, shape.ffn_dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+        b2 = torch.zeros(shape.dim, dtype=torch.bfloat16, device=dev)
+        o2 = torch.empty(M, shape.dim, dtype=torch.bfloat16, device=dev)
+        ms2 = time_graph(lambda: ops.gemm(hbuf, w2, b2, out=o2), 20)
+        wq = (torch.randn(3 * shape.dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+        bq = torch.zeros(3 * shape.dim, dtype=torch.bfloat16, device=dev)
+        oq = torch.empty(M, 3 * shape.dim, dtype=torch.bfloat16, device=dev)
+        ms3 = time_graph(lambda: ops.gemm(a, wq, bq, out=oq), 20)
+        wo = (torch.randn(shape.dim, shape.dim, generator=g) * 0.02).to(torch.bfloat16).to(dev)
+        ms4 = time_graph(lambda: ops.gemm(a, wo, b2, epilogue="resid", resid=o2, out=torch.empty_like(o2)), 20)
+        fl = 2.0 * M * shape.dim * shape.ffn_dim
+        tf = lambda f, ms: f / (ms * 1e-3) / 1e12  # noqa: E731
+        return {"M": M, "C": shape.dim, "ffn": shape.ffn_dim, "ffn0_tflops": tf(fl, ms1), "ffn2_tflops": tf(fl, ms2),
+                "qkv_tflops": tf(2.0 * M * shape.dim * 3 * shape.dim, ms3), "proj_tflops": tf(2.0 * M * shape.dim * shape.dim, ms4),
+                "ffn0_ms": ms1, "ffn2_ms": ms2, "qkv_ms": ms3, "proj_ms": ms4}
+
+    att, gemm = attention_at(batch), gemms_at(batch)
+    if batch != 1:
+        att["at_batch_1"] = attention_at(1)
+        gemm["at_batch_1"] = gemms_at(1)
+    if peaks:
+        att["measured_peaks"] = peaks
     return att, gemm
 
 
-def hbm_bound_leg(shape, dev, nfpb, fs):
+def hbm_bound_leg(shape, dev, nfpb, fs, batch=1, peaks=None):
     """The HBM-bound kernels of a forward (reported as GB/s): algorithmic bytes per launch / mean launch
     duration (50 launches replayed from a HIP graph, events around the replay: back-to-back device time including the
-    ~1.5 us kernel boundary), against the 8 TB/s HBM3E peak.  Shapes of one S1 forward."""
+    ~1.5 us kernel boundary), against the 8 TB/s HBM3E peak and the streaming-copy rate measured on this box.  Shapes of
+    one S1 forward at `batch` prompts per call."""
     HBM_PEAK = 8000.0
-    n, C, H = nfpb * fs, shape.dim, shape.num_heads
+    n, C, H = batch * nfpb * fs, shape.dim, shape.num_heads
+    groups = batch * nfpb
     g = torch.Generator(device="cpu").manual_seed(2)
     rb = lambda *s_: torch.randn(*s_, generator=g).to(torch.bfloat16).to(dev)  # noqa: E731
-    x, mod, e0 = rb(n, C), rb(6, C), rb(nfpb, 6 * C)
-    res = {}
+    x, mod, e0 = rb(n, C), rb(6, C), rb(groups, 6 * C)
+    res = {"batch": batch}
+    copy_peak = peaks.get("hbm_copy_GBps") if peaks else None
+    if copy_peak:
+        res["hbm_measured_peak_GBps"] = copy_peak
 
     def add(name, ms, nbytes, what):
         gbs = nbytes / (ms * 1e-3) / 1e9
         res[name] = {"GBps": gbs, "frac_of_8TBps": gbs / HBM_PEAK, "us": 1e3 * ms, "algorithmic_bytes": nbytes, "bytes": what}
+        if copy_peak:
+            res[name]["frac_of_measured_copy"] = gbs / copy_peak
 
     ms = time_graph(lambda: ops.layernorm_modulate(x, mod[0], mod[1], e0[:, :C], e0[:, C:2 * C], fs), 50)
     add("layernorm_kernel (LN + AdaLN modulate)", ms, 2 * n * C * 2, "x read + y written")
     qkv = rb(n, 3 * C)
-    kc = torch.zeros(1, n, H, 128, dtype=torch.bfloat16, device=dev)
+    kc = torch.zeros(batch, nfpb * fs, H, 128, dtype=torch.bfloat16, device=dev)
     vc = torch.zeros_like(kc)
     nq, nk = rb(C), rb(C)
     from self_forcing_amd.model import rope_tables
     cos, sin = (t.to(dev) for t in rope_tables(128))
     ms = time_graph(lambda: ops.qkv_norm_rope_cache(qkv, nq, nk, kc, vc, cos, sin, (nfpb, LAT_H // 2, LAT_W // 2), 0, 0), 50)
     add("qkv_norm_rope_cache_kernel (QK-RMSNorm + RoPE + cache append)", ms, 6 * n * C * 2, "qkv read; q, K rows, V rows written")
-    xs, w6, b6 = rb(nfpb, C), rb(6 * C, C), rb(6 * C)
+    xs, w6, b6 = rb(groups, C), rb(6 * C, C), rb(6 * C)
     ms = time_graph(lambda: ops.small_linear(xs, w6, b6, act_in="silu"), 50)
-    add("small_linear_kernel (time projection, M = 3)", ms, 6 * C * C * 2, "weights read once")
+    add(f"small_linear_kernel (time projection, M = {groups})", ms, 6 * C * C * 2, "weights read once")
     return res
 
 
@@ -304,8 +374,7 @@ def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
                                 "forward_seconds": dt}}
 
 
-def main():
-    global LAT_H, LAT_W
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -325,22 +394,41 @@ def main():
                     help="latent frames of the 50-step CFG sampler leg (SURVEY 8f-4); 0 skips it, 21 = the whole clip (~20 s)")
     ap.add_argument("--streams", type=int, default=2, help="rollouts in flight per GPU (one HIP stream each, shared weights)")
     ap.add_argument("--batch", type=int, default=2, help="prompts per rollout call (batch dimension of every kernel)")
-    a = ap.parse_args()
-    LAT_H, LAT_W = a.latent_height, a.latent_width
+    ap.add_argument("--rollout-only", action="store_true",
+                    help="timed region only: no roofline / VAE / streaming / sampler / CPU legs (profiling runs)")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="run the multi-rank protocol on CPU over gloo with no GPU work and print its report (tests)")
+    ap.add_argument("--launch-timeout", type=float, default=None, help="seconds the self-launched rank processes may take")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+
+def main():
+    global LAT_H, LAT_W
+    a = parse_args()
+    from self_forcing_amd import distributed as sfd
+    if a.gpus > 1 and not sfd.launched_by_torchrun():
+        # started the way the N = 1 bench is started: become the launcher.  The rank processes are fresh children of
+        # torch.distributed.run; this process has made no GPU call (nothing above touches the device) and only waits.
+        log(f"--gpus {a.gpus} without a torchrun environment: starting {a.gpus} rank processes")
+        raise SystemExit(sfd.self_launch(os.path.abspath(__file__), sys.argv[1:], a.gpus, timeout=a.launch_timeout))
+    rank, local_rank, world = sfd.env_rank_world()
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without torchrun)")
+    if a.dist_selftest:
+        rep = sfd.selftest(steps=a.steps, warmup=a.warmup)
+        if rank == 0:
+            print(json.dumps(rep), flush=True)
+        return
+    LAT_H, LAT_W = a.latent_height, a.latent_width
+    if a.rollout_only:
+        a.no_roofline = a.no_vae = a.no_cpu_baseline = True
+        a.cfg_frames = 0
+
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL over xGMI
+    grp = sfd.RankGroup(backend="nccl", device=dev)             # RCCL over xGMI; no process group at world == 1
 
-    torch.set_num_threads(min(usable_cores(), 16))
+    torch.set_num_threads(max(1, min(usable_cores() // max(1, world), 16)))
     log(f"rank {rank}/{world} on {dev}; synthesising weights")
     shape = sfa.NAMED_SHAPES[a.model]
     nfpb, step_list, shift = 3, [1000, 750, 500, 250], 5.0      # configs/self_forcing_dmd.yaml:9-18,56,69-70
@@ -354,12 +442,8 @@ def main():
     enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=dev)
     pool = sfa.RolloutPool(args, dev, gen, lambda: enc, sfa.IdentityVAE, streams=a.streams)
 
-    if dist is not None:  # every rank must hold the same replica: compare a checksum over RCCL
-        cs = torch.stack([t.float().sum() for t in gen.model._keep[:64]]).sum().reshape(1).double()
-        lo, hi = cs.clone(), cs.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        assert lo.item() == hi.item(), "weight replicas differ across ranks"
+    # every rank must hold the same replica: a checksum of the device-resident weights, compared over RCCL
+    grp.check_replicas(float(torch.stack([t.float().sum() for t in gen.model._keep[:64]]).sum().double().item()))
 
     total = a.warmup + a.steps
     B = a.batch
@@ -376,44 +460,44 @@ def main():
         return pipe.inference(noise, prompts[B * i:B * i + B], return_latents=True, profile=a.profile and rank == 0)[1]
 
     log(f"model resident ({gen.model.param_bytes() / 1e9:.2f} GB); warmup x{a.warmup}, {a.streams} stream(s)")
+    # the board sampler starts a rocm-smi process every 0.5 s: inside the timed region only when this is the one rank
+    # of the job; with several ranks it watches the warm-up instead (same kernels, no effect on the timed region)
+    board = BoardSampler(local_rank) if rank == 0 else None
     tw = time.perf_counter()
+    if board is not None and world > 1:
+        board.__enter__()
     # every stream's pipeline must have seen one rollout (cache / workspace allocation) before timing
     if a.warmup:
         pool.run_each(lambda pipe: one_step(pipe, 0))
         pool.run(list(range(min(a.streams, a.warmup), a.warmup)), one_step)
     torch.cuda.synchronize()
-    log(f"warmup: {time.perf_counter() - tw:.2f} s")
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    board = BoardSampler(local_rank) if rank == 0 else None
-    if board is not None:
-        board.__enter__()
-    t0 = time.perf_counter()
-    lats = pool.run(list(range(a.warmup, total)), one_step)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if board is not None:
+    if board is not None and world > 1:
         board.__exit__()
-    log(f"timed {a.steps} steps in {elapsed:.2f} s")
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    log(f"warmup: {time.perf_counter() - tw:.2f} s")
+    from self_forcing_amd.torch_ops import host_enqueue_stats
+    host_enqueue_stats(reset=True)
+    if board is not None and world == 1:
+        board.__enter__()
+    elapsed, local_elapsed, lats = grp.timed(lambda: pool.run(list(range(a.warmup, total)), one_step))
+    if board is not None and world == 1:
+        board.__exit__()
+    fw_calls, fw_secs, fw_threads = host_enqueue_stats()
+    log(f"timed {a.steps} steps in {local_elapsed:.2f} s (max over ranks {elapsed:.2f} s)")
     lat = lats[-1]
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
     lat = lat[:1]                                               # the legs below work on ONE prompt's latents
-
     decoded = DECODED_PER_LATENT(a.frames)                      # per prompt
+    per_rank = grp.gather([a.steps * B * decoded, local_elapsed, fw_calls, fw_secs])
+    grp.finish()                                                # last collective; rank 0's legs below run alone
+    if rank != 0:
+        return
+
     fps = world * a.steps * B * decoded / elapsed
     flops = B * rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window)
     flops_exec = B * rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window, executed=True)
     # one rollout ALONE on the GPU (one stream): the same step, nothing in flight beside it
     one = None
-    if rank == 0 and (a.streams > 1 or B > 1):
+    if a.streams > 1 or B > 1:
         def single(i):
             noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
             return pool.pipes[0].inference(noise, [prompts[i]], return_latents=True)[1]
@@ -444,21 +528,38 @@ def main():
         "mfma_frac_end_to_end": flops_exec * a.steps / elapsed / 1e12 / MFMA_PEAK_TFLOPS,
         "flop_note": "algorithmic = the reference's (n_steps + 1) full forwards per chunk (SURVEY 8d); executed = minus what the "
                      "context passes skip behind the last layer's K/V write (cache_only); achieved / frac divide EXECUTED work",
+        # host side of one rank (with no data-path collective only start-up skew and host contention can cost
+        # scaling): wall time this rank's threads spent INSIDE sf_dit_forward (the C call that enqueues a pass's launches)
+        "host_threads": a.streams,
+        "host_enqueue_ms_per_forward": 1e3 * fw_secs / max(1, fw_calls),
+        "host_enqueue_busy_cores": fw_secs / max(local_elapsed, 1e-9),
+        "host_cores_available": usable_cores(),
+        "host_note": f"{fw_calls} forwards enqueued by {fw_threads} Python thread(s) in the timed region on rank 0; busy_cores = "
+                     "seconds inside sf_dit_forward / wall seconds (the C call releases the GIL; the Python around it is extra)",
     }
+    if world > 1:
+        out["per_rank"] = {"frames": [r[0] for r in per_rank], "seconds": [r[1] for r in per_rank],
+                           "host_enqueue_ms_per_forward": [1e3 * r[3] / max(1.0, r[2]) for r in per_rank]}
     if board is not None and board.summary() is not None:
         out["board"] = board.summary()
+        out["board"]["sampled_during"] = "the timed region" if world == 1 else "the warm-up steps (several ranks: nothing but the rollout runs in the timed region)"
     if one is not None:
         out["value_one_stream"] = decoded / one
         out["ms_per_rollout_one_stream"] = 1e3 * one
         out["achieved_tflops_one_stream"] = flops_exec / B / one / 1e12
         out["one_stream_note"] = "ONE prompt (batch 1) rolled out alone on the GPU, one HIP stream: the latency configuration"
-    if rank == 0 and not a.no_roofline:
-        log("roofline leg")
-        att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs, window)
+    if not a.no_roofline:
+        log("measured ceilings + roofline leg")
+        peaks = measured_peaks(dev)
+        att, gemm = roofline_leg(shape, dev, a.frames, nfpb, fs, window, batch=B, peaks=peaks)
         out["roofline"] = att
         out["gemm"] = gemm
-        out["hbm_bound"] = hbm_bound_leg(shape, dev, nfpb, fs)
-    if rank == 0 and not a.no_vae:
+        out["mfma_frac_end_to_end_of_measured_peak"] = out["achieved_tflops_per_gpu"] / att["measured_peak"]
+        out["hbm_bound"] = hbm_bound_leg(shape, dev, nfpb, fs, batch=B, peaks=peaks)
+        if B != 1:
+            out["hbm_bound"]["at_batch_1"] = hbm_bound_leg(shape, dev, nfpb, fs, batch=1, peaks=peaks)
+    heavy = world == 1                  # the legs below describe one GPU; the scaling runs (N > 1) skip them
+    if heavy and not a.no_vae:
         # VAE decode: decode alone, then rollout + decode through the same pool
         log("vae decode leg")
         from self_forcing_amd import vae_weights as vw
@@ -492,7 +593,7 @@ def main():
                              "note": "Wan2.1 VAE decoder shape, random-init weights; not part of `value`, whose timed "
                                      "region is the DiT rollout (SURVEY 8d); the second rate is rollout + decode "
                                      "through the same streams, pixels left in HBM"}
-    if rank == 0 and not a.no_roofline:
+    if heavy and not a.no_roofline:
         # streaming boundary: chunk-at-a-time generation on one stream, wall time per chunk
         # (with the real VAE when the leg above installed it: the chunk's pixels are decoded before the yield)
         log("streaming leg")
@@ -510,16 +611,20 @@ def main():
                             "decoded_frames_per_chunk": 4 * nfpb, "steady_fps": 4 * nfpb * len(steady) / sum(steady),
                             "worst_chunk_fps": 4 * nfpb / max(steady), "realtime_playback_fps": 16,
                             "pixels_decoded": not a.no_vae,
-                            "note": "one rollout alone on the GPU, each chunk denoised then decoded to pixels before it is yielded"}
+                            "note": "one rollout alone on the GPU, each chunk denoised then decoded to pixels before it is yielded "
+                                    "(the default; `overlap_decode=True` is an option that measured within noise of it)"}
         if not a.no_vae:   # decode of chunk k on a second HIP stream under the denoising of chunk k+1
-            torch.cuda.synchronize()
-            t_start = time.perf_counter()
-            n_chunks = sum(1 for _ in pipe0.stream(noise, [prompts[0]], overlap_decode=True))
-            torch.cuda.synchronize()
-            out["streaming"]["overlapped_decode_clip_fps"] = decoded / (time.perf_counter() - t_start)
-            out["streaming"]["serial_decode_clip_fps"] = decoded / sum(ts)
-            assert n_chunks == len(ts)
-    if rank == 0 and not a.no_roofline and a.cfg_frames > 0:
+            clip_s = {}
+            for mode in (False, True, False, True):                  # interleaved A/B, best of two each
+                torch.cuda.synchronize()
+                t_start = time.perf_counter()
+                n_chunks = sum(1 for _ in pipe0.stream(noise, [prompts[0]], overlap_decode=mode))
+                torch.cuda.synchronize()
+                clip_s[mode] = min(clip_s.get(mode, 1e9), time.perf_counter() - t_start)
+                assert n_chunks == len(ts)
+            out["streaming"]["overlapped_decode_clip_fps"] = decoded / clip_s[True]
+            out["streaming"]["serial_decode_clip_fps"] = decoded / clip_s[False]
+    if heavy and not a.no_roofline and a.cfg_frames > 0:
         # 50-step UniPC + classifier-free guidance over the same generator: 2 x 50 + 2 forwards per chunk
         log("cfg sampler leg")
         cargs = SimpleNamespace(num_train_timestep=1000, timestep_shift=shift, independent_first_frame=False,
@@ -548,13 +653,9 @@ def main():
                               "note": "CausalDiffusionInferencePipeline: UniPC (order 2) + guidance, prompt / negative-prompt "
                                       "passes on two HIP streams (`seconds_one_stream`: back to back); first "
                                       f"{cfg_frames} latent frames of a clip, so the cache is at most {cfg_frames * fs} tokens long"}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if heavy and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(shape, sd, nfpb, nfpb, len(step_list), a.frames)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_HIP_ABI_VERSION 7
+#define SF_HIP_ABI_VERSION 8
 
 int sf_abi_version(void);
 const char* sf_last_error(void);
@@ -196,7 +196,8 @@ typedef struct sf_model {
   const void *head_w, *head_b;            /* [4*out_dim, C] */
   const void* head_mod;                   /* [2, C] */
   const void *pose_w, *pose_b;            /* optional pose_proj Linear(pose_dim, C) (causal_model.py:493-503); NULL if absent */
-  int32_t pose_dim;
+  int32_t pose_dim;                       /* width of add_condition; with pose_w == NULL and pose_dim == dim the projection is
+                                             the reference's nn.Identity() of dim-5120 models (:500-501): x += add_condition */
   const sf_layer_weights* layers_host;    /* HOST array [num_layers] */
   const float *rope_cos, *rope_sin;       /* float32 [1024, 64] */
   const float *sched_sigmas, *sched_timesteps; /* float32 [n_table] */
@@ -233,6 +234,11 @@ typedef struct sf_forward_args {
   void* x0_out;                           /* [B, F, out_dim, H, W] */
   void* workspace;
   size_t workspace_bytes;
+  void* kv_index_out;                     /* optional int64 [num_layers][2]: every row is set to (global_end, attn_end) at
+                                             the end of the pass -- the cache dicts' "global_end_index" / "local_end_index"
+                                             tensors (causal_model.py:235-236) when they are views of one buffer; NULL:
+                                             the caller updates its index tensors itself */
+  int64_t global_end;                     /* current_start + F*h*w (only written to kv_index_out) */
 } sf_forward_args;
 
 size_t sf_dit_workspace_bytes(const sf_model* model, int batch, int frames, int lat_h, int lat_w,
@@ -421,6 +427,19 @@ size_t sf_t5_workspace_bytes(const sf_t5_model* model, int batch, int seq_len);
  * out bf16 [batch][seq_len][dim], rows past each prompt's length zero. */
 int sf_t5_encode(const sf_t5_model* model, const int64_t* ids, const int64_t* mask, const int32_t* rel_bucket,
                  int batch, int seq_len, void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measured ceilings of the box ("Peaks to divide by": "re-measure on the box (a peak-MFMA micro-kernel
+ * and a streaming-copy kernel) and use the measured ceilings in the fraction").  Measurement entry points for
+ * bench.py (roofline.measured_peak, hbm_measured_peak); no product kernel depends on them and the reference has no
+ * counterpart.
+ *   sf_probe_mfma: `workgroups` x 4 waves each issue iters x 32 v_mfma_f32_32x32x16_bf16 (shape 0) or iters x 64
+ *                  v_mfma_f32_16x16x32_bf16 (shape 1) from registers, 4 independent accumulators; `operands` = 8 KiB
+ *                  of (random) bf16, `sink` = workgroups * 256 floats; *flops_out (HOST, optional) = flops of the launch.
+ *   sf_probe_copy: streaming copy of `bytes` (multiple of 16) from src to dst, 16 bytes per lane. */
+int sf_probe_mfma(int shape, int iters, int workgroups, const void* operands, float* sink, double* flops_out_host,
+                  void* stream);
+int sf_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,8 @@ from oracle.make_golden import LAT_H, LAT_W, bf16_randn, build_model, f32, fresh
 import self_forcing_amd as sfa  # noqa: E402
 
 RANK, ALPHA, B_STD = 8, 4.0, 0.5     # B_STD: adapters that change the weights by ~40 % (the output by ~10 %)
+B_STD_SMALL = 0.05                   # second set: weights moved by ~4 % (a few bf16 ulps of W), the output by ~1 % -- the
+                                     # merged-then-rounded matrices must still carry the adapters (keys `*_small`)
 TARGETS = ["q", "k", "v", "o", "ffn.0", "ffn.2"]
 
 
@@ -35,9 +37,9 @@ def main():
     from safetensors.torch import save_file
     shape = sfa.WAN_REDUCED
     sd = sfa.synth_state_dict(shape, seed=0)
-    lora = sfa.synth_lora_state_dict(shape, RANK, seed=11, targets=TARGETS, b_std=B_STD)
     fs = (LAT_H // 2) * (LAT_W // 2)
-    out = {"weights_seed": np.array(0), "lora_seed": np.array(11), "rank": np.array(RANK), "alpha": np.array(ALPHA), "b_std": np.array(B_STD)}
+    out = {"weights_seed": np.array(0), "lora_seed": np.array(11), "rank": np.array(RANK), "alpha": np.array(ALPHA), "b_std": np.array(B_STD),
+           "b_std_small": np.array(B_STD_SMALL)}
     gf = torch.Generator().manual_seed(131)
     pe = bf16_randn((1, 512, shape.text_dim), gf)
     pe[:, 66:] = 0
@@ -46,32 +48,34 @@ def main():
     t1 = torch.tensor([[937.5, 833.3333129882812]], dtype=torch.float32)
     t2 = torch.tensor([[625.0, 625.0, 250.0]], dtype=torch.float32)
     out.update(pe=f32(pe), x1=f32(x1), x2=f32(x2), t1=f32(t1), t2=f32(t2))
-    with tempfile.TemporaryDirectory() as tmp:
-        path = os.path.join(tmp, "adapters.safetensors")
-        save_file({"diffusion_model." + k: v.contiguous() for k, v in lora.items()}, path)
-        for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-            m = build_model(ns, shape, sd, dtype)
-            replaced = rl.apply_lora(m, rank=RANK, alpha=ALPHA, dropout=0.0, target_modules=TARGETS)
-            loaded, skipped = rl.load_lora_weights(m, lora_path=path, alpha=ALPHA)
-            assert replaced == 10 * shape.num_layers and loaded == replaced and skipped == 0, (replaced, loaded, skipped)
-            m.eval()
-            kvs, cas = fresh_caches(shape, 1, 5 * fs, dtype)
-            with torch.no_grad():
-                y1 = m(x1.to(dtype), t=t1, context=pe.to(dtype), seq_len=32760, kv_cache=kvs, crossattn_cache=cas,
-                       current_start=0, cache_start=None)
-                y2 = m(x2.to(dtype), t=t2, context=pe.to(dtype), seq_len=32760, kv_cache=kvs, crossattn_cache=cas,
-                       current_start=2 * fs, cache_start=None)
-                # the same model WITHOUT adapters (how much LoRA moves the output: the test must not be vacuous)
-                m0 = build_model(ns, shape, sd, dtype)
-                kv0, ca0 = fresh_caches(shape, 1, 5 * fs, dtype)
-                y1_base = m0(x1.to(dtype), t=t1, context=pe.to(dtype), seq_len=32760, kv_cache=kv0, crossattn_cache=ca0,
-                             current_start=0, cache_start=None)
-            out[f"y1_{tag}"], out[f"y2_{tag}"] = f32(y1), f32(y2)
-            out[f"k0_{tag}"], out[f"v1_{tag}"] = f32(kvs[0]["k"]), f32(kvs[1]["v"])
-            out[f"ck1_{tag}"] = f32(cas[1]["k"][:, :80])
-            d = ((y1.float() - y1_base.float()).norm() / y1_base.float().norm()).item()
-            out[f"lora_effect_{tag}"] = np.array(d)
-            print(tag, "replaced", replaced, "loaded", loaded, "LoRA moves the output by rel", round(d, 4))
+    for sfx, b_std in (("", B_STD), ("_small", B_STD_SMALL)):
+        lora = sfa.synth_lora_state_dict(shape, RANK, seed=11, targets=TARGETS, b_std=b_std)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "adapters.safetensors")
+            save_file({"diffusion_model." + k: v.contiguous() for k, v in lora.items()}, path)
+            for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+                m = build_model(ns, shape, sd, dtype)
+                replaced = rl.apply_lora(m, rank=RANK, alpha=ALPHA, dropout=0.0, target_modules=TARGETS)
+                loaded, skipped = rl.load_lora_weights(m, lora_path=path, alpha=ALPHA)
+                assert replaced == 10 * shape.num_layers and loaded == replaced and skipped == 0, (replaced, loaded, skipped)
+                m.eval()
+                kvs, cas = fresh_caches(shape, 1, 5 * fs, dtype)
+                with torch.no_grad():
+                    y1 = m(x1.to(dtype), t=t1, context=pe.to(dtype), seq_len=32760, kv_cache=kvs, crossattn_cache=cas,
+                           current_start=0, cache_start=None)
+                    y2 = m(x2.to(dtype), t=t2, context=pe.to(dtype), seq_len=32760, kv_cache=kvs, crossattn_cache=cas,
+                           current_start=2 * fs, cache_start=None)
+                    # the same model WITHOUT adapters (how much LoRA moves the output: the test must not be vacuous)
+                    m0 = build_model(ns, shape, sd, dtype)
+                    kv0, ca0 = fresh_caches(shape, 1, 5 * fs, dtype)
+                    y1_base = m0(x1.to(dtype), t=t1, context=pe.to(dtype), seq_len=32760, kv_cache=kv0, crossattn_cache=ca0,
+                                 current_start=0, cache_start=None)
+                out[f"y1_{tag}{sfx}"], out[f"y2_{tag}{sfx}"] = f32(y1), f32(y2)
+                out[f"k0_{tag}{sfx}"], out[f"v1_{tag}{sfx}"] = f32(kvs[0]["k"]), f32(kvs[1]["v"])
+                out[f"ck1_{tag}{sfx}"] = f32(cas[1]["k"][:, :80])
+                d = ((y1.float() - y1_base.float()).norm() / y1_base.float().norm()).item()
+                out[f"lora_effect_{tag}{sfx}"] = np.array(d)
+                print(tag, sfx or "(large)", "replaced", replaced, "loaded", loaded, "LoRA moves the output by rel", round(d, 4))
     d = np.linalg.norm(out["y2_bf16"] - out["y2_f32"]) / np.linalg.norm(out["y2_f32"])
     print("reference bf16 (unmerged) vs fp32: %.4f" % d)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lora_reduced.npz"), **out)

@@ -1,8 +1,8 @@
 """Import the reference's hot-path modules on CPU (build container only).
 
-TEST INFRASTRUCTURE.  Used by `oracle/make_golden.py` (fixture generation) and by
-`tests/test_oracle_vs_reference.py` (skipped wherever /root/reference is absent, e.g.
-on the GPU box).  Nothing from the reference is copied: this file only arranges for
+TEST INFRASTRUCTURE.  Used by the fixture generators `oracle/make_golden*.py` only (the tests
+compare against the committed fixtures; /root/reference does not exist on the GPU box).
+Nothing from the reference is copied: this file only arranges for
 `import` to succeed despite packages that are not installed here.
 """
 from __future__ import annotations

@@ -370,7 +370,12 @@ def forward_inference(W: Dict[str, Tensor], cfg: OracleConfig, x: Tensor, t: Ten
         # training branch (causal_model.py:980-994).
         if add_condition.shape[1] != tok.shape[1]:
             raise ValueError(f"add_condition spatial dim {add_condition.shape[1]} doesn't match x spatial dim {tok.shape[1]}")
-        tok = tok + F.linear(add_condition.to(dtype), W["pose_proj.weight"], W["pose_proj.bias"])
+        if "pose_proj.weight" in W:
+            tok = tok + F.linear(add_condition.to(dtype), W["pose_proj.weight"], W["pose_proj.bias"])
+        else:   # dim == 5120: `pose_proj = nn.Identity()` (causal_model.py:500-503) -- a plain add of the pose tokens
+            if add_condition.shape[2] != tok.shape[2]:
+                raise ValueError(f"no pose_proj weights: add_condition must be {tok.shape[2]} wide, got {add_condition.shape[2]}")
+            tok = tok + add_condition.to(dtype)
     e, e0 = time_embeddings(W, cfg, t, dtype)
     ctx = text_embedding(W, cfg, context.to(dtype))
     h = tok

@@ -22,7 +22,7 @@ from .text_encoder import WanTextEncoder, UMT5Encoder, relative_position_buckets
 from . import unipc  # noqa: F401
 from .diffusion_pipeline import CausalDiffusionInferencePipeline  # noqa: F401
 from .unipc import FlowUniPCMultistepScheduler  # noqa: F401
-from . import ops, _lib, torch_ops, text_encoder  # noqa: F401
+from . import ops, _lib, torch_ops, text_encoder, distributed  # noqa: F401
 
 __all__ = ["WanShape", "WAN_1_3B", "WAN_14B", "WAN_REDUCED", "NAMED_SHAPES", "synth_state_dict",
            "param_shapes", "merge_lora", "strip_prefix", "synth_lora_state_dict", "apply_lora_file", "load_lora_file",

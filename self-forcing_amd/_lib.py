@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # epilogue codes (enum sf_epilogue)
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_GATE_RESID, EPI_F32 = 0, 1, 2, 3, 4
@@ -79,6 +79,7 @@ class ForwardArgs(C.Structure):
         ("cache_only", C.c_int32),
         ("flow_out", C.c_void_p), ("x0_out", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("kv_index_out", C.c_void_p), ("global_end", C.c_int64),
     ]
 
 
@@ -160,6 +161,8 @@ SIGNATURES = {
     "sf_zero_masked_rows": (C.c_int, [_vp, _vp, _i, _i, _vp]),
     "sf_t5_workspace_bytes": (C.c_size_t, [C.POINTER(T5Model), _i, _i]),
     "sf_t5_encode": (C.c_int, [C.POINTER(T5Model), _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "sf_probe_mfma": (C.c_int, [_i, _i, _i, _vp, _vp, C.POINTER(C.c_double), _vp]),
+    "sf_probe_copy": (C.c_int, [_vp, _vp, _sz, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -10,6 +10,8 @@
 #include "sf_common.h"
 #include "../../include/sf_hip.h"
 
+int sf_internal_write_kv_indices(void* buf, int layers, int64_t global_end, int64_t local_end, void* stream);   // elementwise.hip
+
 namespace {
 
 struct Carve {
@@ -110,8 +112,16 @@ extern "C" int sf_dit_forward(const sf_model* m, const sf_forward_args* a, void*
 
   // ---- pose conditioning of the fork: x += pose_proj(add_condition)  (causal_model.py:786-819)
   if (a->add_condition) {
-    SF_CHECK(m->pose_w && m->pose_dim > 0, "sf_dit_forward: add_condition given but the model has no pose_proj weights");
-    SF_TRY(gemm(a->add_condition, m->pose_dim, m->pose_w, m->pose_b, ws.x, C, M, C, m->pose_dim, SF_EPI_BIAS_RESID, ws.x, C, nullptr, nullptr, 0, 1, stream));
+    if (m->pose_w) {
+      SF_CHECK(m->pose_dim > 0, "sf_dit_forward: pose_proj weights without pose_dim");
+      SF_TRY(gemm(a->add_condition, m->pose_dim, m->pose_w, m->pose_b, ws.x, C, M, C, m->pose_dim, SF_EPI_BIAS_RESID, ws.x, C, nullptr, nullptr, 0, 1, stream));
+    } else {
+      // dim == 5120: `pose_proj = nn.Identity()` (causal_model.py:500-503): x += add_condition, [M, C] bf16, fp32 add, one rounding
+      SF_CHECK(m->pose_dim == C, "sf_dit_forward: add_condition without pose_proj weights needs pose_dim == dim (%d != %d)", m->pose_dim, C);
+      const void* terms[2] = {ws.x, a->add_condition};
+      const float ones[2] = {1.0f, 1.0f};
+      SF_TRY(sf_lincomb_bf16(ws.x, terms, ones, 2, (int64_t)M * C, stream));
+    }
   }
 
   // ---- time embeddings: e [BG, C], e0 [BG, 6C]
@@ -149,7 +159,10 @@ extern "C" int sf_dit_forward(const sf_model* m, const sf_forward_args* a, void*
     }
     SF_TRY(sf_qkv_norm_rope_cache(ws.qkv, lw.norm_q_w, lw.norm_k_w, ws.q, a->k_cache_host[l], a->v_cache_host[l], m->rope_cos, m->rope_sin,
                                   B, F, h, w, C, m->num_heads, a->cache_tokens, a->write_start, a->start_frame, m->eps, stream));
-    if (a->cache_only && l == m->num_layers - 1) return 0;   // nothing downstream of this K/V write is read
+    if (a->cache_only && l == m->num_layers - 1) {           // nothing downstream of this K/V write is read
+      if (a->kv_index_out) SF_TRY(sf_internal_write_kv_indices(a->kv_index_out, m->num_layers, a->global_end, a->attn_end, stream));
+      return 0;
+    }
     SF_TRY(sf_attention(ws.q, bptr(a->k_cache_host[l], (size_t)a->attn_start * C), bptr(a->v_cache_host[l], (size_t)a->attn_start * C), ws.att,
                         B, m->num_heads, L, a->attn_end - a->attn_start, C, (long)L * C, C, cache_b, C, (long)L * C, stream));
     SF_TRY(gemm(ws.att, C, lw.o_w, lw.o_b, ws.x, C, M, C, C, SF_EPI_BIAS_GATE_RESID, ws.x, C, bptr(mod, 2 * (size_t)C), bptr(ws.e0, 2 * (size_t)C),
@@ -174,5 +187,6 @@ extern "C" int sf_dit_forward(const sf_model* m, const sf_forward_args* a, void*
   SF_TRY(gemm(ws.xn, C, m->head_w, m->head_b, ws.headout, Nh, M, Nh, C, SF_EPI_BIAS, nullptr, 0, nullptr, nullptr, 0, 1, stream));
   SF_TRY(sf_unpatchify_x0(ws.headout, a->noisy, a->timestep, a->t_is_int64, m->sched_sigmas, m->sched_timesteps, m->n_table, a->flow_out,
                           a->x0_out, B, F, G, m->out_dim, a->lat_h, a->lat_w, stream));
+  if (a->kv_index_out) SF_TRY(sf_internal_write_kv_indices(a->kv_index_out, m->num_layers, a->global_end, a->attn_end, stream));
   return 0;
 }

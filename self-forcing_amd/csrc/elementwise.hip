@@ -546,6 +546,19 @@ extern "C" int sf_lincomb_bf16(void* out, const void* const* xs, const float* co
   return 0;
 }
 
+// the cache dicts' index tensors (causal_model.py:235-236), all layers at once: buf int64 [layers][2] <- (global_end, local_end)
+__global__ void kv_index_kernel(long long* __restrict__ buf, int layers, long long global_end, long long local_end) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * layers) buf[i] = (i & 1) ? local_end : global_end;
+}
+// (library-internal: called by sf_dit_forward only)
+__attribute__((visibility("hidden"))) int sf_internal_write_kv_indices(void* buf, int layers, int64_t global_end, int64_t local_end, void* stream) {
+  hipLaunchKernelGGL(kv_index_kernel, dim3((2 * layers + 63) / 64), dim3(64), 0, (hipStream_t)stream, (long long*)buf, layers,
+                     (long long)global_end, (long long)local_end);
+  SF_HIP_LAUNCH_CHECK("kv_index_kernel");
+  return 0;
+}
+
 extern "C" int sf_sinusoid_embedding(const void* t, int t_is_int64, void* out, int n, int dim, void* stream) {
   SF_CHECK(t && out && n > 0 && dim > 0 && dim % 2 == 0, "sf_sinusoid_embedding: bad arguments");
   const int total = n * (dim / 2);

@@ -47,6 +47,7 @@ def _new_kv_cache(shape, n_layers: int, batch_size: int, cache_tokens: int, dtyp
             "_sf_index_buffer": index_buffer,
         })
     kv[0]["_sf_mirror"] = (kv[0]["global_end_index"], kv[0]["local_end_index"], 0, 0)
+    kv[0]["_sf_index_views"] = [(d["global_end_index"], d["local_end_index"]) for d in kv]
     return kv
 
 

@@ -83,10 +83,14 @@ class CausalWanModel:
             setattr(m, dst + "_w", P(self._dev(sd[src + ".weight"])))
             setattr(m, dst + "_b", P(self._dev(sd[src + ".bias"])))
         m.head_mod = P(self._dev(sd["head.modulation"].reshape(2, s.dim)))
+        from .weights import POSE_DIM
         self.has_pose_proj = "pose_proj.weight" in sd
         if self.has_pose_proj:   # optional: the fork's pose conditioning (Linear(5120, dim), causal_model.py:493-503)
             m.pose_w, m.pose_b = P(self._dev(sd["pose_proj.weight"])), P(self._dev(sd["pose_proj.bias"]))
             m.pose_dim = sd["pose_proj.weight"].shape[1]
+        elif s.dim == POSE_DIM:  # `pose_proj = nn.Identity()` for dim-5120 models (:500-501): no weights, x += add_condition
+            m.pose_dim = s.dim
+        self.accepts_pose = self.has_pose_proj or s.dim == POSE_DIM
         layers = (_lib.LayerWeights * s.num_layers)()
         for i in range(s.num_layers):
             p = f"blocks.{i}."
@@ -135,14 +139,16 @@ class CausalWanModel:
     def forward(self, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], init_cross: bool,
                 k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor], plan: CachePlan,
                 start_frame: int, evict_scratch: Optional[Tensor] = None, cache_only: bool = False,
-                add_condition: Optional[Tensor] = None):
+                add_condition: Optional[Tensor] = None, kv_index: Optional[Tensor] = None):
         """noisy [B,F,in_dim,H,W] bf16 (contiguous); timestep [B,G] float32|int64 on device; *_cache: per-layer cache
-        tensors (mutated in place).  Returns (flow, x0) [B,F,out_dim,H,W], or (None, None) with cache_only.
+        tensors (mutated in place); kv_index: the shared int64 [L, 2] buffer behind the cache dicts' index tensors (the
+        pass ends by setting every row to (plan.global_end, plan.local_end)), or None.  Returns (flow, x0)
+        [B,F,out_dim,H,W], or (None, None) with cache_only.
         ONE custom-op call: torch.ops.sf_hip.dit_forward -> sf_dit_forward."""
         B, F, Cin, H, W = noisy.shape
         ws = self.workspace(B, F, H, W, timestep.shape[1])
         flow, x0 = torch.ops.sf_hip.dit_forward(
             self._handle, noisy, timestep, prompt_embeds, add_condition, k_cache, v_cache, ck_cache, cv_cache, ws, evict_scratch,
             bool(init_cross), bool(cache_only), plan.sink, plan.evict, plan.keep, plan.write_start, plan.attn_start, plan.local_end,
-            start_frame)
+            start_frame, kv_index, plan.global_end)
         return (None, None) if cache_only else (flow, x0)

@@ -258,3 +258,28 @@ def softmax_rows(s: Tensor, scale: float, cols_padded: Optional[int] = None) -> 
     check(lib().sf_softmax_rows(s.data_ptr(), s.stride(0), out.data_ptr(), cp, rows, cols, cp, float(scale), stream_handle()),
           "sf_softmax_rows")
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# measured ceilings of the box (bench.py: roofline.measured_peak / hbm_measured_peak)
+def probe_mfma(operands: Tensor, sink: Tensor, shape: str = "32x32x16", iters: int = 2000, workgroups: int = 256) -> float:
+    """Launches the register-only bf16 MFMA loop (sf_probe_mfma) on the current stream; returns the launch's FLOPs.
+    operands: >= 4096 bf16 (random); sink: >= workgroups * 256 float32."""
+    _bf16(operands, "operands")
+    if operands.numel() < 4096 or sink.dtype != torch.float32 or sink.numel() < workgroups * 256 or not sink.is_cuda:
+        raise ValueError("probe_mfma: operands >= 4096 bf16 and a CUDA float32 sink of workgroups * 256 elements expected")
+    fl = C.c_double(0.0)
+    check(lib().sf_probe_mfma({"32x32x16": 0, "16x16x32": 1}[shape], iters, workgroups, operands.data_ptr(), sink.data_ptr(),
+                              C.byref(fl), stream_handle()), "sf_probe_mfma")
+    return fl.value
+
+
+def probe_copy(src: Tensor, dst: Tensor) -> int:
+    """Streaming copy src -> dst (sf_probe_copy) on the current stream; returns the bytes READ (as many are written)."""
+    if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()):
+        raise ValueError("probe_copy: contiguous CUDA tensors expected")
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst.numel() * dst.element_size() or nbytes % 16:
+        raise ValueError("probe_copy: src and dst must hold the same number of bytes, a multiple of 16")
+    check(lib().sf_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, stream_handle()), "sf_probe_copy")
+    return nbytes

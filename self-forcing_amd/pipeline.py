@@ -166,13 +166,12 @@ class CausalInferencePipeline(torch.nn.Module):
             total = init_time + diffusion_time + vae_time
             self.last_profile = {"init_ms": init_time, "diffusion_ms": diffusion_time, "vae_ms": vae_time,
                                  "block_ms": blocks, "total_ms": total}
-            print("Profiling results:")
-            print(f"  - Initialization/caching time: {init_time:.2f} ms ({100 * init_time / total:.2f}%)")
-            print(f"  - Diffusion generation time: {diffusion_time:.2f} ms ({100 * diffusion_time / total:.2f}%)")
-            for i, bt in enumerate(blocks):
-                print(f"    - Block {i} generation time: {bt:.2f} ms ({100 * bt / diffusion_time:.2f}% of diffusion)")
-            print(f"  - VAE decoding time: {vae_time:.2f} ms ({100 * vae_time / total:.2f}%)")
-            print(f"  - Total time: {total:.2f} ms")
+            share = lambda part, whole: 100.0 * part / max(whole, 1e-9)  # noqa: E731
+            report = [f"rollout profile: {total:.1f} ms = cache setup {init_time:.1f} ms ({share(init_time, total):.1f} %) + "
+                      f"denoising {diffusion_time:.1f} ms ({share(diffusion_time, total):.1f} %) + decode {vae_time:.1f} ms "
+                      f"({share(vae_time, total):.1f} %)"]
+            report += [f"  chunk {i}: {bt:.1f} ms ({share(bt, diffusion_time):.1f} % of denoising)" for i, bt in enumerate(blocks)]
+            print("\n".join(report))
 
         if return_latents:
             return video, output
@@ -187,33 +186,38 @@ class CausalInferencePipeline(torch.nn.Module):
         the final chunk when `skip_last_context`, as demo.py:396 does: nothing reads that update)."""
         gen = self.generator
         batch_size = noise.shape[0]
-        # one host->device copy per rollout: a pageable H2D copy per step drains the stream (the host then waits for
-        # the GPU and the next forward is enqueued late: 0.2-0.5 ms of idle GPU per forward in the rocprofv3 trace)
+        # Every timestep tensor of the rollout is built HERE, once: the reference builds `ones([B, f], int64) * t` for each
+        # forward and `t_next * ones([B * f], long)` for each re-noise (causal_inference.py:190-216, :228) -- three small
+        # launches per step of kernels this library does not own.  One host->device copy of the step list, one broadcast
+        # per distinct chunk length; the loop below then launches nothing of torch's but `randn_like` (the reference's
+        # global-RNG re-noise, :208, which must stay) and the caller's copy of the chunk into `output`.
         steps = self.denoising_step_list.to(noise.device)
         ctx_noise = getattr(self.args, "context_noise", 0)
+        tables = {}
+        for f in set(all_num_frames):
+            ones = torch.ones([batch_size, f], device=noise.device, dtype=torch.int64)
+            per_step = (ones.unsqueeze(0) * steps.reshape(-1, 1, 1)).contiguous()      # [S, B, f], dtype as `ones * t`
+            tables[f] = (list(per_step.unbind(0)), [t.flatten() for t in per_step.unbind(0)],
+                         torch.ones_like(per_step[0]) * ctx_noise)
+        n_steps = steps.shape[0]
         for chunk_idx, current_num_frames in enumerate(all_num_frames):
             if on_chunk_start is not None:
                 on_chunk_start()
             noisy_input = noise[:, current_start_frame - num_input_frames:
                                 current_start_frame + current_num_frames - num_input_frames]
             start_tok = current_start_frame * self.frame_seq_length
-            for index, current_timestep in enumerate(steps):
-                timestep = torch.ones([batch_size, current_num_frames], device=noise.device, dtype=torch.int64) \
-                    * current_timestep
+            step_ts, step_ts_flat, context_timestep = tables[current_num_frames]
+            for index in range(n_steps):
                 _, denoised_pred = gen(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
-                                       timestep=timestep, kv_cache=self.kv_cache1,
+                                       timestep=step_ts[index], kv_cache=self.kv_cache1,
                                        crossattn_cache=self.crossattn_cache, current_start=start_tok)
-                if index < len(steps) - 1:
-                    next_timestep = steps[index + 1]
+                if index < n_steps - 1:
                     flat = denoised_pred.flatten(0, 1)
-                    noisy_input = self.scheduler.add_noise(
-                        flat, self._randn_like(flat),
-                        next_timestep * torch.ones([batch_size * current_num_frames], device=noise.device, dtype=torch.long)
-                    ).unflatten(0, denoised_pred.shape[:2])
+                    noisy_input = self.scheduler.add_noise(flat, self._randn_like(flat), step_ts_flat[index + 1]
+                                                           ).unflatten(0, denoised_pred.shape[:2])
             yield chunk_idx, current_start_frame, denoised_pred
             # rerun at the context timestep so the cache holds clean K/V (causal_inference.py:226-235)
             if not (skip_last_context and chunk_idx == len(all_num_frames) - 1):
-                context_timestep = torch.ones_like(timestep) * ctx_noise
                 gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
                     kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok,
                     **self._cache_only_kw)
@@ -311,6 +315,8 @@ class CausalInferencePipeline(torch.nn.Module):
                 "_sf_index_buffer": index_buffer,
             })
         kv_cache1[0]["_sf_mirror"] = (kv_cache1[0]["global_end_index"], kv_cache1[0]["local_end_index"], 0, 0)
+        # the forward call's last kernel writes all 2 x L indices at once while the dicts still hold THESE views
+        kv_cache1[0]["_sf_index_views"] = [(kv["global_end_index"], kv["local_end_index"]) for kv in kv_cache1]
         self.kv_cache1 = kv_cache1
 
     def _reset_kv_indices(self):

@@ -14,7 +14,7 @@ tracing, and is opaque-but-legal to `torch.compile` -- which the reference's sec
     sf_hip::lincomb(tensors[], coefs[]) -> out ;  sf_hip::lincomb_out(out!, tensors[], coefs[]) -> ()
     sf_hip::add_noise(x0, eps, timestep, sigmas, timesteps) -> out
     sf_hip::dit_forward(model, noisy, timestep, prompt_embeds?, add_condition?, k_cache![], v_cache![], ck_cache![],
-                        cv_cache![], workspace!, evict_scratch!?, ...) -> (flow, x0)
+                        cv_cache![], workspace!, evict_scratch!?, ..., kv_index!?, global_end) -> (flow, x0)
     sf_hip::vae_decode_frames(model, state!, scratch!, z, out!, h, w, window_frames, frame_index, window, history_at) -> ()
     sf_hip::t5_encode(model, ids, mask, buckets, workspace!) -> out
 
@@ -24,6 +24,8 @@ Models (weights + C descriptors) are Python objects that own device memory; oper
 from __future__ import annotations
 
 import ctypes as C
+import threading
+import time
 import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -198,14 +200,38 @@ def _(x0, eps, timestep, sigmas, timesteps):
 # ------------------------------------------------------------------------------------------ fused DiT forward
 _TABLES: Dict[int, tuple] = {}
 
+# Host time spent INSIDE sf_dit_forward (the C call that enqueues the ~430 launches of a pass), per calling thread:
+# {thread id: [calls, seconds]}.  bench.py reports it as host_enqueue_ms_per_forward -- with one process per GPU and
+# `streams` enqueuing threads per process, 8 ranks x that many threads must fit the node's cores.
+HOST_ENQUEUE: Dict[int, list] = {}
 
-def _pointer_tables(handle: int, k: Sequence[Tensor], v: Sequence[Tensor], ck: Sequence[Tensor], cv: Sequence[Tensor]):
-    """Per-layer cache pointer arrays for the C call; rebuilt only when a cache tensor was re-allocated / rebound."""
-    key = tuple(t.data_ptr() for t in k) + tuple(t.data_ptr() for t in v) + tuple(t.data_ptr() for t in ck) + tuple(t.data_ptr() for t in cv)
-    slot = (handle, torch.cuda.current_stream(k[0].device).cuda_stream)
+
+def host_enqueue_stats(reset: bool = False):
+    """(forwards, seconds, threads) summed over the threads that called dit_forward since the last reset."""
+    calls = sum(v[0] for v in HOST_ENQUEUE.values())
+    secs = sum(v[1] for v in HOST_ENQUEUE.values())
+    n = sum(1 for v in HOST_ENQUEUE.values() if v[0])
+    if reset:
+        HOST_ENQUEUE.clear()
+    return calls, secs, n
+
+
+def _pointer_tables(handle: int, k: Sequence[Tensor], v: Sequence[Tensor], ck: Sequence[Tensor], cv: Sequence[Tensor],
+                    want_kv: tuple, want_cross: tuple, device):
+    """Per-layer cache pointer arrays for the C call; rebuilt -- and every tensor validated (bf16, contiguous, the
+    expected [B, S, H, D] on the call's device: the kernels WRITE through these pointers) -- only when a cache tensor
+    was re-allocated / rebound or the expected shape changed."""
+    key = (want_kv, want_cross) + tuple(t.data_ptr() for t in k) + tuple(t.data_ptr() for t in v) + tuple(t.data_ptr() for t in ck) \
+        + tuple(t.data_ptr() for t in cv)
+    slot = (handle, torch.cuda.current_stream(device).cuda_stream)
     hit = _TABLES.get(slot)
     if hit is not None and hit[0] == key:
         return hit[1]
+    for name, tensors, want in (("k_cache", k, want_kv), ("v_cache", v, want_kv), ("ck_cache", ck, want_cross), ("cv_cache", cv, want_cross)):
+        for i, t in enumerate(tensors):
+            if not t.is_cuda or t.dtype != torch.bfloat16 or tuple(t.shape) != want or not t.is_contiguous() or t.device != device:
+                raise ValueError(f"dit_forward: {name}[{i}] must be a contiguous bf16 tensor {want} on {device}, got "
+                                 f"{tuple(t.shape)} {t.dtype} {t.device}")
     arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
     tabs = (arr(k), arr(v), arr(ck), arr(cv))
     if len(_TABLES) > 64:
@@ -215,14 +241,16 @@ def _pointer_tables(handle: int, k: Sequence[Tensor], v: Sequence[Tensor], ck: S
 
 
 @custom_op(f"{NAMESPACE}::dit_forward",
-           mutates_args=("k_cache", "v_cache", "ck_cache", "cv_cache", "workspace", "evict_scratch"))
+           mutates_args=("k_cache", "v_cache", "ck_cache", "cv_cache", "workspace", "evict_scratch", "kv_index"))
 def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], add_condition: Optional[Tensor],
                 k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor],
                 workspace: Tensor, evict_scratch: Optional[Tensor], init_cross: bool, cache_only: bool, sink: int, evict: int,
-                keep: int, write_start: int, attn_start: int, attn_end: int, start_frame: int) -> Tuple[Tensor, Tensor]:
+                keep: int, write_start: int, attn_start: int, attn_end: int, start_frame: int,
+                kv_index: Optional[Tensor], global_end: int) -> Tuple[Tensor, Tensor]:
     """One denoiser pass (CausalWanModel._forward_inference + flow -> x0, sf_dit_forward).  Writes the new K/V rows
     into k_cache / v_cache (and, with init_cross, the text K/V into ck_cache / cv_cache); returns (flow, x0), or two
-    empty tensors with cache_only."""
+    empty tensors with cache_only.  kv_index (optional, int64 [num_layers, 2]): every row <- (global_end, attn_end),
+    the cache dicts' index tensors when they are views of one buffer."""
     m = _model(model)
     _need_gpu(noisy, "noisy")
     _need_gpu(timestep, "timestep", None)
@@ -234,8 +262,32 @@ def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Opti
     if not (len(k_cache) == len(v_cache) == len(ck_cache) == len(cv_cache) == L):
         raise ValueError(f"dit_forward: cache lists must have {L} entries")
     B, F, _, H, W = noisy.shape
-    cap = k_cache[0].shape[1]
-    k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = _pointer_tables(model, k_cache, v_cache, ck_cache, cv_cache)
+    sh = m.shape
+    if noisy.shape[2] != sh.in_dim or timestep.shape[0] != B:
+        raise ValueError(f"dit_forward: noisy must carry {sh.in_dim} channels and timestep one row per sample")
+    cap = k_cache[0].shape[1] if k_cache[0].dim() == 4 else -1
+    # the C call writes through these pointers: every cache tensor must really be what the kernels assume (checked when
+    # the pointer tables are (re)built, i.e. whenever any cache tensor is new to this model / stream)
+    want_kv, want_cross = (B, cap, sh.num_heads, sh.head_dim), (B, sh.text_len, sh.num_heads, sh.head_dim)
+    n_new = F * (H // 2) * (W // 2)
+    if not (0 <= attn_start < attn_end <= cap and 0 <= write_start and write_start + n_new == attn_end):
+        raise ValueError(f"dit_forward: cache plan does not fit the cache (write_start {write_start} + {n_new} new tokens, "
+                         f"window [{attn_start}, {attn_end}), capacity {cap})")
+    if init_cross:
+        if prompt_embeds is None:
+            raise ValueError("dit_forward: init_cross needs prompt_embeds")
+        _need_gpu(prompt_embeds, "prompt_embeds")
+        if tuple(prompt_embeds.shape) != (B, sh.text_len, sh.text_dim) or not prompt_embeds.is_contiguous():
+            raise ValueError(f"dit_forward: prompt_embeds must be contiguous [{B}, {sh.text_len}, {sh.text_dim}], got {tuple(prompt_embeds.shape)}")
+    if add_condition is not None:
+        _need_gpu(add_condition, "add_condition")
+        if add_condition.dim() != 3 or add_condition.shape[:2] != (B, n_new) or not add_condition.is_contiguous():
+            raise ValueError(f"dit_forward: add_condition must be contiguous [{B}, {n_new}, pose_dim], got {tuple(add_condition.shape)}")
+    if not workspace.is_cuda or workspace.dtype != torch.uint8 or not workspace.is_contiguous():
+        raise ValueError("dit_forward: workspace must be a contiguous CUDA uint8 tensor")
+    if evict_scratch is not None and (not evict_scratch.is_cuda or evict_scratch.dtype != torch.uint8 or not evict_scratch.is_contiguous()):
+        raise ValueError("dit_forward: evict_scratch must be a contiguous CUDA uint8 tensor")
+    k_ptrs, v_ptrs, ck_ptrs, cv_ptrs = _pointer_tables(model, k_cache, v_cache, ck_cache, cv_cache, want_kv, want_cross, noisy.device)
     a = _lib.ForwardArgs()
     a.batch, a.frames, a.lat_h, a.lat_w, a.groups = B, F, H, W, timestep.shape[1]
     a.noisy, a.timestep = noisy.data_ptr(), timestep.data_ptr()
@@ -258,13 +310,24 @@ def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Opti
         x0 = torch.empty_like(flow)
         a.flow_out, a.x0_out = flow.data_ptr(), x0.data_ptr()
     a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-    _lib.check(_lib.lib().sf_dit_forward(C.byref(m.cmodel), C.byref(a), _stream(noisy)), "sf_dit_forward")
+    if kv_index is not None:
+        if kv_index.dtype != torch.int64 or not kv_index.is_cuda or not kv_index.is_contiguous() or tuple(kv_index.shape) != (L, 2):
+            raise ValueError(f"dit_forward: kv_index must be a contiguous CUDA int64 [{L}, 2] tensor")
+        a.kv_index_out, a.global_end = kv_index.data_ptr(), global_end
+    fn, st = _lib.lib().sf_dit_forward, _stream(noisy)
+    t0 = time.perf_counter()
+    rc = fn(C.byref(m.cmodel), C.byref(a), st)
+    dt = time.perf_counter() - t0
+    rec = HOST_ENQUEUE.setdefault(threading.get_ident(), [0, 0.0])
+    rec[0] += 1
+    rec[1] += dt
+    _lib.check(rc, "sf_dit_forward")
     return flow, x0
 
 
 @dit_forward.register_fake
 def _(model, noisy, timestep, prompt_embeds, add_condition, k_cache, v_cache, ck_cache, cv_cache, workspace, evict_scratch,
-      init_cross, cache_only, sink, evict, keep, write_start, attn_start, attn_end, start_frame):
+      init_cross, cache_only, sink, evict, keep, write_start, attn_start, attn_end, start_frame, kv_index, global_end):
     if cache_only:
         return noisy.new_empty((0,)), noisy.new_empty((0,))
     B, F, _, H, W = noisy.shape
@@ -285,6 +348,18 @@ def vae_decode_frames(model: int, state: Tensor, scratch: Tensor, z: Tensor, out
     _need_gpu(out, "out", torch.float32)
     if z.dim() != 4 or not z.is_contiguous() or not out.is_contiguous():
         raise ValueError("vae_decode_frames: contiguous z [F, z_dim, h, w] and out expected")
+    if tuple(z.shape[1:]) != (m.shape.z_dim, h, w):
+        raise ValueError(f"vae_decode_frames: z must be [F, {m.shape.z_dim}, {h}, {w}], got {tuple(z.shape)}")
+    for name, t in (("state", state), ("scratch", scratch)):       # their element counts are passed on as BYTE counts
+        if not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+            raise ValueError(f"vae_decode_frames: {name} must be a contiguous CUDA uint8 tensor")
+    sf_, tf_ = m.shape.spatial_factor, m.shape.temporal_factor
+    frames = 1 if frame_index == 0 else tf_ * z.shape[0]
+    if frame_index == 0 and z.shape[0] != 1:
+        raise ValueError("vae_decode_frames: the frame that follows a reset (frame_index 0) is decoded alone")
+    if out.numel() < frames * 3 * (sf_ * h) * (sf_ * w):
+        raise ValueError(f"vae_decode_frames: out holds {out.numel()} floats, {frames} frames of 3 x {sf_ * h} x {sf_ * w} need "
+                         f"{frames * 3 * sf_ * h * sf_ * w}")
     _lib.check(_lib.lib().sf_vae_decode_frames(C.byref(m.cmodel), state.data_ptr(), state.numel(), scratch.data_ptr(), scratch.numel(),
                                                z.data_ptr(), h, w, window_frames, frame_index, z.shape[0], window, history_at,
                                                out.data_ptr(), _stream(z)),

@@ -41,6 +41,16 @@ def repack_conv(w: Tensor, cin_pad: Optional[int] = None) -> Tensor:
     return out
 
 
+class _StreamPos:
+    """Where one latent size's stream stands since its last reset."""
+    __slots__ = ("fresh", "nframes", "slot")
+
+    def __init__(self):
+        self.fresh = True      # no chunk decoded since the last clear_cache
+        self.nframes = 0       # latent frames decoded since then
+        self.slot = 0          # ... of them in the current lap of the sliding history windows (sf_vae_decode_frames)
+
+
 class WanVAEDecoder:
     """Device-resident decoder: repacked bf16 weights, the C model descriptor, and one decode state
     (the convolution histories of one stream).  Counterpart of `WanVAE_` (wan/modules/vae.py:478-617)
@@ -56,9 +66,7 @@ class WanVAEDecoder:
         self._keep: List[Tensor] = []
         self._state: Dict[tuple, Tensor] = {}
         self._scratch: Dict[tuple, Tensor] = {}
-        self._fresh = True     # no chunk decoded since the last clear_cache
-        self._nframes = 0      # latent frames decoded since then
-        self._slot = 0         # ... of them in the current lap of the sliding history windows (sf_vae_decode_frames)
+        self._pos: Dict[tuple, _StreamPos] = {}     # per latent size, beside its state: where that stream stands
         self._load(state_dict)
 
     # ---------------------------------------------------------------------------------
@@ -148,8 +156,7 @@ class WanVAEDecoder:
             if n == 0:
                 _lib.check(-1, "sf_vae_state_bytes")
             self._state[key] = torch.zeros(n, dtype=torch.uint8, device=self.device)
-            self._fresh = True
-            self._nframes = self._slot = 0
+            self._pos[key] = _StreamPos()          # every latent size streams on its own: counters live beside its state
         skey = (h, w, torch.cuda.current_stream(self.device).cuda_stream)
         if skey not in self._scratch:
             n = _lib.lib().sf_vae_scratch_bytes(C.byref(self.cmodel), h, w, self.window_frames)
@@ -161,12 +168,20 @@ class WanVAEDecoder:
         stream = torch.cuda.current_stream(self.device).cuda_stream if self._state else None
         for (h, w), st in self._state.items():
             _lib.check(_lib.lib().sf_vae_reset(C.byref(self.cmodel), st.data_ptr(), st.numel(), h, w, self.window_frames, stream), "sf_vae_reset")
-        self._fresh = True
-        self._nframes = self._slot = 0
+            self._pos[(h, w)] = _StreamPos()
 
-    def frames_out(self, latent_frames: int) -> int:
+    def frames_out(self, latent_frames: int, h: Optional[int] = None, w: Optional[int] = None) -> int:
+        """Pixel frames the next `cached_decode` of `latent_frames` frames of an h x w latent returns (the size may be
+        omitted while the decoder has seen at most one)."""
         tf = self.shape.temporal_factor
-        return (1 + tf * (latent_frames - 1)) if self._fresh else tf * latent_frames
+        if h is None:
+            if len(self._pos) > 1:
+                raise ValueError("frames_out: this decoder streams several latent sizes; pass h and w")
+            pos = next(iter(self._pos.values()), None)
+        else:
+            pos = self._pos.get((h, w))
+        fresh = pos is None or pos.fresh
+        return (1 + tf * (latent_frames - 1)) if fresh else tf * latent_frames
 
     def cached_decode(self, z: Tensor) -> Tensor:
         """`WanVAE_.cached_decode` (vae.py:579-593) for one sample: z [F, z_dim, h, w] bf16 -> float32
@@ -176,25 +191,26 @@ class WanVAEDecoder:
         z = z.to(device=self.device, dtype=torch.bfloat16).contiguous()
         F, _, h, w = z.shape
         state, scratch = self._buffers(h, w)
+        pos = self._pos[(h, w)]
         sf, tf = self.shape.spatial_factor, self.shape.temporal_factor
-        out = torch.empty(self.frames_out(F), 3, sf * h, sf * w, dtype=torch.float32, device=self.device)
+        out = torch.empty(self.frames_out(F, h, w), 3, sf * h, sf * w, dtype=torch.float32, device=self.device)
         t0 = i = 0
         while i < F:
             # the frame that follows a reset is decoded alone (one output frame); after it, groups of up to
             # frames_per_call latent frames per C call -- bit-identical to one call per frame, but the low-resolution
             # stages fill the chip and every launch has a shorter tail
-            g = 1 if self._fresh else min(self.frames_per_call, F - i)
-            if self._slot + g > self.window_frames:
-                window, history_at = 0, self._slot
+            g = 1 if pos.fresh else min(self.frames_per_call, F - i)
+            if pos.slot + g > self.window_frames:
+                window, history_at = 0, pos.slot
             else:
-                window = history_at = self._slot
+                window = history_at = pos.slot
             torch.ops.sf_hip.vae_decode_frames(self._handle, state, scratch, z[i:i + g], out[t0:], h, w, self.window_frames,
-                                               self._nframes, window, history_at)
-            self._slot = window + g
-            self._nframes += g
-            t0 += 1 if self._fresh else tf * g
+                                               pos.nframes, window, history_at)
+            pos.slot = window + g
+            pos.nframes += g
+            t0 += 1 if pos.fresh else tf * g
             i += g
-            self._fresh = False
+            pos.fresh = False
         return out
 
     def decode(self, z: Tensor) -> Tensor:

@@ -126,15 +126,24 @@ class WanDiffusionWrapper(torch.nn.Module):
         return int(d["global_end_index"].item()), int(d["local_end_index"].item())
 
     @staticmethod
-    def _write_indices(kv_cache: List[dict], global_end: int, local_end: int) -> None:
+    def _shared_index_buffer(kv_cache: List[dict]) -> Optional[Tensor]:
+        """The int64 [L, 2] buffer all layers' index tensors are views of (caches built by our pipeline,
+        `_initialize_kv_cache`), while the dicts still hold those very views; None for foreign or rebound caches."""
         d0 = kv_cache[0]
-        buf = d0.get("_sf_index_buffer")
-        if buf is not None and all(kv.get("_sf_index_buffer") is buf for kv in kv_cache) and \
-                d0["global_end_index"].data_ptr() == buf.data_ptr():
-            # all layers' index tensors are views of one buffer [L, 2]: two fills update them all
-            buf[:, 0].fill_(global_end)
-            buf[:, 1].fill_(local_end)
-        else:
+        buf, views = d0.get("_sf_index_buffer"), d0.get("_sf_index_views")
+        if buf is None or views is None or len(views) != len(kv_cache):
+            return None
+        for kv, (g, l) in zip(kv_cache, views):
+            if kv["global_end_index"] is not g or kv["local_end_index"] is not l:
+                return None
+        return buf
+
+    @staticmethod
+    def _write_indices(kv_cache: List[dict], global_end: int, local_end: int, done_by_kernel: bool = False) -> None:
+        """causal_model.py:235-236.  With the shared buffer the forward call's last kernel has written every row
+        (`kv_index_out`); foreign caches get the reference's per-layer fills.  The host mirror is refreshed either way."""
+        d0 = kv_cache[0]
+        if not done_by_kernel:
             for kv in kv_cache:
                 kv["global_end_index"].fill_(global_end)
                 kv["local_end_index"].fill_(local_end)
@@ -210,19 +219,20 @@ class WanDiffusionWrapper(torch.nn.Module):
 
         if add_condition is not None:   # pose tokens [B, L_pose, 5120]: x += pose_proj(add_condition), the intent of
             # causal_model.py:786-819 (that branch raises in the reference snapshot: parity pinned by the oracle only)
-            if not mdl.has_pose_proj:
-                raise NotImplementedError("add_condition needs pose_proj weights in the state dict "
-                                          "(dim == 5120 models use an identity projection, which is not implemented)")
+            if not mdl.accepts_pose:   # (dim == 5120 models need none: their pose_proj is nn.Identity(), :500-501)
+                raise ValueError(f"add_condition needs pose_proj weights in the state dict of a dim-{shape.dim} model")
             add_condition = add_condition.to(device=mdl.device, dtype=torch.bfloat16).contiguous()
             if add_condition.dim() != 3 or add_condition.shape[0] != B or add_condition.shape[1] != n_new:
                 raise ValueError(f"add_condition spatial dim {add_condition.shape[1]} doesn't match "
                                  f"x spatial dim {n_new}. Check pose data processing.")
             assert add_condition.shape[2] == mdl.cmodel.pose_dim, "add_condition channel width must match pose_proj"
+        index_buf = self._shared_index_buffer(kv_cache)
         flow, x0 = mdl.forward(x, t, pe, init_cross, [kv["k"] for kv in kv_cache], [kv["v"] for kv in kv_cache],
                                [c["k"] for c in crossattn_cache], [c["v"] for c in crossattn_cache], plan,
-                               current_start // fs, scratch, cache_only=cache_only, add_condition=add_condition)
+                               current_start // fs, scratch, cache_only=cache_only, add_condition=add_condition,
+                               kv_index=index_buf)
         if init_cross:
             for c in crossattn_cache:
                 c["is_init"] = True
-        self._write_indices(kv_cache, plan.global_end, plan.local_end)
+        self._write_indices(kv_cache, plan.global_end, plan.local_end, done_by_kernel=index_buf is not None)
         return flow, x0

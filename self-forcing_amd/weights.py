@@ -222,10 +222,12 @@ def apply_lora_file(sd: Dict[str, Tensor], lora_sd: Dict[str, Tensor], s: WanSha
     dropping an optional `.default`, a known prefix and a trailing `.weight` -- is one of the wrapped Linears,
     W += (alpha / rank) * up @ down.  `rank` is the CONSTRUCTOR's rank, as in the reference (`module.scaling =
     alpha / module.rank`, :228-230), not the file's.  Pairs for other modules are skipped, as the reference skips them.
-    Returns (state dict, loaded, skipped)."""
+    A file without a single (up, down) pair raises ValueError as `load_lora_weights` does (:150-152); a file whose pairs
+    all miss the wrapped Linears (a mis-prefixed or foreign adapter file) would leave the base model running silently:
+    that case warns.  Returns (state dict, loaded, skipped)."""
     wrapped = set(lora_target_linears(s, targets))
     out = dict(sd)
-    loaded = skipped = 0
+    loaded = skipped = pairs = 0
     scale = alpha / rank
     for key_up in lora_sd:
         if "lora_B" in key_up:
@@ -236,6 +238,7 @@ def apply_lora_file(sd: Dict[str, Tensor], lora_sd: Dict[str, Tensor], s: WanSha
             continue
         if key_down not in lora_sd:
             continue
+        pairs += 1
         parts = key_up.split(".")
         tok = "lora_B" if "lora_B" in parts else "lora_up" if "lora_up" in parts else None
         if tok is None:
@@ -265,4 +268,10 @@ def apply_lora_file(sd: Dict[str, Tensor], lora_sd: Dict[str, Tensor], s: WanSha
         up, down = up.to(W.dtype).float(), down.to(W.dtype).float()
         out[target + ".weight"] = (W.float() + scale * (up @ down)).to(W.dtype)
         loaded += 1
+    if pairs == 0:
+        raise ValueError("No LoRA pairs found (expected lora_A/lora_B or lora_up/lora_down).")
+    if loaded == 0:
+        import warnings
+        warnings.warn(f"LoRA file holds {pairs} adapter pair(s) but NONE maps to a wrapped Linear of this model (targets "
+                      f"{sorted(set(targets))}; first key: {next(iter(lora_sd))!r}): the base model runs unchanged", stacklevel=2)
     return out, loaded, skipped

@@ -363,6 +363,129 @@ def test_rollout_bit_reproducible_beside_vae_convolutions(sd_reduced):
         assert torch.equal(lat, ref)
 
 
+def test_add_condition_identity_projection_on_dim_5120_models():
+    """`pose_proj = nn.Identity()` when dim == 5120 (causal_model.py:500-501; BASELINE configs[4] is that model): the pose
+    tokens are added to the patch embedding as they are.  Two layers of the 14B geometry (40 heads of 128; ffn cut to
+    2048 so the fp32 CPU oracle stays quick) against the oracle -- oracle-only like the rest of this branch (parity
+    unpinned: the reference snapshot raises on it)."""
+    shape = sfa.WanShape(dim=5120, ffn_dim=2048, num_heads=40, num_layers=2)
+    sd = sfa.synth_state_dict(shape, seed=3, pose=True)
+    assert "pose_proj.weight" not in sd                      # nothing to load for the identity
+    g = torch.Generator().manual_seed(56)
+    pe = torch.randn(1, 512, shape.text_dim, generator=g).to(torch.bfloat16)
+    pe[:, 90:] = 0
+    x = torch.randn(1, 2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16)
+    cond = (0.5 * torch.randn(1, 2 * FS, 5120, generator=g)).to(torch.bfloat16)
+    t = torch.tensor([[833.3333129882812, 625.0]])
+    gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=5.0, is_causal=True, device=DEV)
+    assert gen.model.accepts_pose and not gen.model.has_pose_proj
+    args = SimpleNamespace(denoising_step_list=[1000], warp_denoising_step=False, independent_first_frame=False,
+                           num_frame_per_block=1, context_noise=0)
+    pipe = sfa.CausalInferencePipeline(args, DEV, generator=gen, text_encoder=sfa.FixedTextEncoder(pe.to(DEV)), vae=sfa.IdentityVAE())
+    pipe.frame_seq_length = FS
+    outs = []
+    for c in (cond, None):
+        pipe._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=2 * FS)
+        pipe._initialize_crossattn_cache(1, torch.bfloat16, DEV)
+        cd = {"prompt_embeds": pe.to(DEV)}
+        if c is not None:
+            cd["add_condition"] = c.to(DEV)
+        outs.append(gen(x.to(DEV), cd, t.to(DEV), pipe.kv_cache1, pipe.crossattn_cache, 0)[0])
+    Wf = wo.prepare_weights(sd, torch.float32)
+    cfg = wo.OracleConfig(dim=shape.dim, ffn_dim=shape.ffn_dim, num_heads=shape.num_heads, num_layers=shape.num_layers,
+                          text_dim=shape.text_dim)
+    for out, c in zip(outs, (cond, None)):
+        kv, ca = wo.init_kv_cache(cfg, 1, 2 * FS, torch.float32), wo.init_crossattn_cache(cfg, 1, torch.float32)
+        ref = wo.wrapper_forward(Wf, cfg, wo.FlowMatchTables(5.0), x.float(), pe.float(), t, kv, ca, 0,
+                                 add_condition=None if c is None else c.float())[0]
+        assert rel(out, ref) < TOL
+    assert rel(outs[0], outs[1]) > 0.05
+    with pytest.raises(ValueError, match="spatial dim"):
+        gen(x.to(DEV), {"prompt_embeds": pe.to(DEV), "add_condition": cond[:, :-1].to(DEV)}, t.to(DEV), pipe.kv_cache1,
+            pipe.crossattn_cache, 0)
+    # a dim-1536 model WITHOUT pose_proj weights cannot take pose tokens: refused, not guessed
+    small = sfa.WanDiffusionWrapper(shape=sfa.WAN_REDUCED, state_dict=sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0), timestep_shift=5.0,
+                                    is_causal=True, device=DEV)
+    p2 = sfa.CausalInferencePipeline(args, DEV, generator=small, text_encoder=sfa.FixedTextEncoder(pe.to(DEV)), vae=sfa.IdentityVAE())
+    p2.frame_seq_length = FS
+    p2._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=2 * FS)
+    p2._initialize_crossattn_cache(1, torch.bfloat16, DEV)
+    with pytest.raises(ValueError, match="needs pose_proj weights"):
+        small(x.to(DEV), {"prompt_embeds": pe.to(DEV), "add_condition": cond.to(DEV)}, t.to(DEV), p2.kv_cache1, p2.crossattn_cache, 0)
+
+
+def _conv_corunner(g):
+    """The co-runner that triggered the packed-fp32 fault: a 3x3x3 convolution whose gathered
+    k-loop is 54 slices long; returns a function that enqueues `n` of them on the current stream."""
+    from self_forcing_amd.vae import repack_conv
+    xc = torch.randn(6, 64, 96, 64, generator=g).to(torch.bfloat16).to(DEV)
+    wc = repack_conv((torch.randn(64, 64, 3, 3, 3, generator=g) * 0.05).to(torch.bfloat16)).to(DEV)
+    bc = torch.randn(64, generator=g).to(torch.bfloat16).to(DEV)
+
+    def run(n):
+        for _ in range(n):
+            sfa.ops.conv_igemm(xc, wc, bc, (3, 3, 3), 4)
+    return run
+
+
+def test_torch_renoise_kernels_bit_reproducible_beside_vae_convolutions():
+    """The kernels of torch's that a rollout still launches (the library does not own them and they are built with the
+    SLP vectoriser ON): `torch.randn_like` -- the reference's global-RNG re-noise, causal_inference.py:208, which must
+    stay torch's -- and the once-per-rollout `ones * t` broadcast.  Large tensors (thousands of waves, so that many share
+    a CU with the convolution's waves), fixed seed: alone vs beside the 54-slice convolution, bit for bit."""
+    g = torch.Generator().manual_seed(43)
+    conv = _conv_corunner(g)
+    side = torch.cuda.Stream(device=DEV)
+    like = torch.empty(8, 16, 480, 832, dtype=torch.bfloat16, device=DEV)        # 49 M elements
+    steps = torch.tensor([1000.0, 937.5, 833.3333, 625.0], device=DEV)
+    ones = torch.ones([64, 4096], dtype=torch.int64, device=DEV)
+
+    def torch_kernels():
+        torch.manual_seed(777)
+        a = torch.randn_like(like)
+        b = torch.randn(3, 1 << 22, device=DEV)                                  # fp32 normal: the other template
+        c = (ones.unsqueeze(0) * steps.reshape(-1, 1, 1)).contiguous()
+        return a, b, c
+
+    ref = torch_kernels()
+    torch.cuda.synchronize()
+    for _ in range(10):
+        with torch.cuda.stream(side):
+            conv(150)
+        got = torch_kernels()
+        torch.cuda.synchronize()
+        for r, x in zip(ref, got):
+            assert torch.equal(r, x)
+
+
+def test_rollout_with_torch_renoise_bit_reproducible_beside_vae_convolutions(sd_reduced):
+    """The DEFAULT path (noise_source = None: re-noise drawn by torch.randn_like from the global generator) under a fixed
+    seed, alone vs beside the convolution co-runner: the same latents bit for bit.  (The regression test above injects
+    pre-drawn noise and so never ran torch's generator kernel beside a convolution.)"""
+    g = torch.Generator().manual_seed(47)
+    noise = torch.randn(1, 6, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    pipe = make_pipe(sd_reduced, 2, False, 5.0, pe=pe)
+    assert pipe.noise_source is None
+    conv = _conv_corunner(g)
+    side = torch.cuda.Stream(device=DEV)
+
+    def rollout():
+        torch.manual_seed(4242)
+        return pipe.inference(noise, ["p"], return_latents=True)[1].clone()
+
+    ref = rollout()
+    torch.cuda.synchronize()
+    torch.manual_seed(4243)
+    assert not torch.equal(pipe.inference(noise, ["p"], return_latents=True)[1], ref)   # the seed really drives the re-noise
+    for _ in range(10):
+        with torch.cuda.stream(side):
+            conv(200)
+        lat = rollout()
+        torch.cuda.synchronize()
+        assert torch.equal(lat, ref)
+
+
 def test_two_streams_rollout_plus_decode_match_sequential(sd_reduced):
     """RolloutPool with the real VAE in every pipeline: while one stream decodes its clip the other one is still
     denoising (the configuration of bench.py's rollout + decode rate).  Latents and pixels must equal the one-stream

@@ -253,6 +253,31 @@ def test_streaming_decode_equals_one_shot():
     assert torch.equal(torch.cat([c0, c1], 1), whole)
 
 
+def test_streams_of_two_latent_sizes_do_not_share_their_position():
+    """One decoder, two latent sizes streamed chunk by chunk IN TURN: each size keeps its own history state and its own
+    position in it (fresh / frames decoded / window slot).  Sharing the position -- a second size resetting the first
+    one's counters -- would read stale history frames without any error; the pixels must equal each size decoded alone."""
+    shape = vw.VAE_REDUCED
+    sd = vw.synth_vae_state_dict(shape, seed=5)
+    g = torch.Generator().manual_seed(77)
+    la = bf((7, shape.z_dim, 8, 12), g).to(DEV)
+    lb = bf((6, shape.z_dim, 6, 10), g).to(DEV)
+    alone = sfa.WanVAEDecoder(shape, sd, DEV)
+    ref_a, ref_b = alone.decode(la), alone.decode(lb)
+    dec = sfa.WanVAEDecoder(shape, sd, DEV)
+    out_a, out_b = [], []
+    cuts_a, cuts_b = [(0, 1), (1, 4), (4, 7)], [(0, 2), (2, 3), (3, 6)]
+    for (a0, a1), (b0, b1) in zip(cuts_a, cuts_b):
+        assert dec.frames_out(a1 - a0, 8, 12) == ((1 + 4 * (a1 - a0 - 1)) if a0 == 0 else 4 * (a1 - a0))
+        out_a.append(dec.cached_decode(la[a0:a1]))
+        out_b.append(dec.cached_decode(lb[b0:b1]))
+    assert torch.equal(torch.cat(out_a), ref_a) and torch.equal(torch.cat(out_b), ref_b)
+    with pytest.raises(ValueError, match="several latent sizes"):
+        dec.frames_out(1)
+    dec.clear_cache()                                   # resets every size's state AND position
+    assert torch.equal(dec.cached_decode(lb), ref_b) and torch.equal(dec.cached_decode(la[:1]), ref_a[:1])
+
+
 @pytest.mark.parametrize("fpc", [2, 3, 4, 7])
 def test_grouped_frames_are_bit_identical_to_one_frame_per_call(fpc):
     """sf_vae_decode_frames on groups of latent frames (what fills the chip at the low-resolution stages) against the

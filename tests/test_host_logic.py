@@ -179,52 +179,98 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
 
 
 # ------------------------------------------------------------ N > 1 protocol over gloo (CPU)
-_WORKER = r'''
+# These run the code bench.py runs (self_forcing_amd/distributed.py: RankGroup, self_launch, selftest), not a copy.
+def _json_line(stdout):
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line on stdout, got {len(lines)}: {stdout[-800:]}"
+    return json.loads(lines[0])
+
+
+def _check_selftest_report(out, steps):
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["backend"] == "gloo"
+    assert out["prompt_indices_per_rank"] == [[0, 2, 4, 6][:steps + 1], [1, 3, 5, 7][:steps + 1]]   # rank::W, no overlap
+    assert out["units_per_rank"] == [steps, steps]
+    # barrier + MAX over ranks: rank 1 "works" 0.1 s per step, rank 0 half of that
+    assert out["elapsed_s"] >= 0.1 * steps - 1e-3 and out["seconds_per_rank"][1] >= 0.1 * steps - 1e-3
+    assert out["seconds_per_rank"][0] < out["seconds_per_rank"][1]
+    assert abs(out["ms_per_step"] - 1e3 * out["elapsed_s"] / steps) < 1e-6
+
+
+def test_bench_gpus2_self_launch_runs_the_protocol(tmp_path):
+    """`python bench.py --gpus 2 ...` started the way the N = 1 bench is started (no torchrun environment) launches its
+    own two rank processes and prints ONE line; --dist-selftest = the same protocol over gloo with no GPU work."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-selftest", "--steps", "3",
+                          "--launch-timeout", "200"], env=env, capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    _check_selftest_report(_json_line(res.stdout), 3)
+
+
+def test_bench_under_an_existing_torchrun(tmp_path):
+    """The driver's way: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`; and a rank count
+    that does not match --gpus is refused."""
+    port = str(sfa.distributed.free_port())
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+            "--master-port", port, os.path.join(ROOT, "bench.py")]
+    res = subprocess.run(base + ["--gpus", "2", "--dist-selftest", "--steps", "2"], capture_output=True, text=True, timeout=240,
+                         cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    _check_selftest_report(_json_line(res.stdout), 2)
+    res = subprocess.run(base + ["--gpus", "4", "--dist-selftest"], capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
+
+
+_WORKER = r"""
 import os, sys, json, time
-import torch, torch.distributed as dist
+import torch
 sys.path.insert(0, os.environ["SF_ROOT"])
-from self_forcing_amd.sharding import shard_indices
-import self_forcing_amd as sfa
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group(backend="gloo")
-# identical replicas: same seeded weights everywhere, proven with a checksum MIN/MAX all-reduce
-sd = sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0)
-cs = torch.stack([v.double().sum() for v in sd.values()]).sum().reshape(1)
-lo, hi = cs.clone(), cs.clone()
-dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-assert lo.item() == hi.item()
-steps = 3
-idx = shard_indices(steps * world, rank, world)
-dist.barrier()
-t0 = time.perf_counter()
-time.sleep(0.05 * (rank + 1))          # rank-dependent "work": the slowest rank sets the time
-dist.barrier()
-el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-dist.all_reduce(el, op=dist.ReduceOp.MAX)
-seen = [None] * world
-dist.all_gather_object(seen, idx)
-if rank == 0:
-    print(json.dumps({"elapsed": el.item(), "idx": seen, "frames": world * steps * 81}))
-dist.destroy_process_group()
-'''
+from self_forcing_amd.distributed import RankGroup
+grp = RankGroup(backend="gloo", timeout_s=120)
+assert grp.world == 2 and grp.dist is not None
+assert grp.check_replicas(1234.5) == 1234.5
+try:
+    grp.check_replicas(1.0 + grp.rank)           # replicas that differ must be caught on EVERY rank
+    caught = False
+except RuntimeError as e:
+    caught = "replicas differ" in str(e)
+elapsed, local, res = grp.timed(lambda: (time.sleep(0.05 * (grp.rank + 1)), grp.rank * 10)[1])
+rows = grp.gather([float(grp.rank), local, 7.0])
+grp.finish()
+assert grp.dist is None
+if grp.rank == 0:
+    print(json.dumps({"caught": caught, "elapsed": elapsed, "local": local, "res": res, "rows": rows}))
+else:
+    assert caught and res == 10
+"""
 
 
-def test_two_rank_gloo_protocol(tmp_path):
-    """World size 2 on CPU: replica checksum, rank::W prompt assignment with no overlap, barrier +
-    max-over-ranks timing -- the protocol bench.py runs over RCCL."""
+def test_rank_group_two_ranks_gloo(tmp_path):
+    """RankGroup under world size 2: replica check (equal passes, unequal raises everywhere), barrier-bracketed timing
+    with the MAX over ranks, gather, finish."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, SF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    port = str(sfa.distributed.free_port())
+    env = dict(os.environ, SF_ROOT=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", str(script)]
+           "--master-port", port, str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    import json
-    out = json.loads(line)
-    assert out["idx"] == [[0, 2, 4], [1, 3, 5]]
-    assert out["elapsed"] >= 0.1 - 1e-3          # max over ranks: rank 1 slept 0.1 s
-    assert out["frames"] == 2 * 3 * 81
+    out = _json_line(res.stdout)
+    assert out["caught"] and out["res"] == 0
+    assert out["elapsed"] >= 0.1 - 1e-3 > out["local"]            # rank 0 slept 0.05 s, the job took rank 1's 0.1 s
+    assert [r[0] for r in out["rows"]] == [0.0, 1.0] and out["rows"][1][1] >= 0.1 - 1e-3 and out["rows"][0][2] == 7.0
+
+
+def test_rank_group_single_process_is_the_identity():
+    from self_forcing_amd.distributed import RankGroup, launched_by_torchrun
+    assert not launched_by_torchrun() or "RANK" in os.environ
+    grp = RankGroup(backend="gloo")
+    if grp.world == 1:
+        assert grp.dist is None and grp.check_replicas(3.0) == 3.0
+        el, loc, res = grp.timed(lambda: 5)
+        assert res == 5 and el >= loc >= 0 and grp.gather([1, 2]) == [[1.0, 2.0]]
+        grp.finish()
 
 
 # ----------------------------------------------------------------------------------- config
@@ -409,10 +455,10 @@ def test_torch_custom_ops_have_fake_implementations():
         assert tuple(n.shape) == (3, 16, 8, 8)
         caches = [[e(1, 48, 4, 128) for _ in range(2)] for _ in range(2)] + [[e(1, 512, 4, 128) for _ in range(2)] for _ in range(2)]
         flow, x0 = torch.ops.sf_hip.dit_forward(h, e(1, 2, 16, 8, 12), e(1, 2, dt=torch.float32), None, None, *caches,
-                                                e(1024, dt=torch.uint8), None, False, False, 0, 0, 0, 0, 0, 48, 0)
+                                                e(1024, dt=torch.uint8), None, False, False, 0, 0, 0, 0, 0, 48, 0, None, 0)
         assert tuple(flow.shape) == (1, 2, 16, 8, 12) and tuple(x0.shape) == (1, 2, 16, 8, 12)
         flow, x0 = torch.ops.sf_hip.dit_forward(h, e(1, 2, 16, 8, 12), e(1, 2, dt=torch.float32), None, None, *caches,
-                                                e(1024, dt=torch.uint8), None, False, True, 0, 0, 0, 0, 0, 48, 0)
+                                                e(1024, dt=torch.uint8), None, False, True, 0, 0, 0, 0, 0, 48, 0, e(2, 2, dt=torch.int64), 24)
         assert flow.numel() == 0
         t = torch.ops.sf_hip.t5_encode(h, e(2, 512, dt=torch.int64), e(2, 512, dt=torch.int64), e(1023, dt=torch.int32), e(64, dt=torch.uint8))
         assert tuple(t.shape) == (2, 512, 4096) and t.dtype == torch.bfloat16

@@ -66,6 +66,48 @@ def test_merged_weights_reproduce_the_references_unmerged_lora_fp32(G):
     assert loaded == 10 * shape.num_layers and torch.equal(m2["blocks.1.ffn.2.weight"], merged["blocks.1.ffn.2.weight"])
 
 
+def test_files_without_usable_adapters_are_not_silent(G):
+    """A file with no (up, down) pair raises like the reference's load_lora_weights (utils/lora.py:150-152); a file whose
+    pairs all miss the model (wrong prefix / foreign modules) warns instead of silently running the base model."""
+    shape = sfa.WAN_REDUCED
+    sd = sfa.synth_state_dict(shape, seed=0)
+    with pytest.raises(ValueError, match="No LoRA pairs found"):
+        sfa.apply_lora_file(sd, {"blocks.0.self_attn.q.weight": torch.zeros(2, 2)}, shape, 8, 4.0, TARGETS)
+    with pytest.raises(ValueError, match="No LoRA pairs found"):       # an up matrix without its down matrix is no pair
+        sfa.apply_lora_file(sd, {"blocks.0.self_attn.q.lora_B.weight": torch.zeros(2, 2)}, shape, 8, 4.0, TARGETS)
+    foreign = {"unet." + k: v for k, v in _adapters(G).items()}
+    with pytest.warns(UserWarning, match="NONE maps to a wrapped Linear"):
+        out, loaded, skipped = sfa.apply_lora_file(sd, foreign, shape, 8, 4.0, TARGETS)
+    assert loaded == 0 and skipped == 10 * shape.num_layers and all(torch.equal(out[k], sd[k]) for k in sd)
+
+
+def test_small_adapters_survive_the_merge_rounding(G):
+    """Adapters that move the weights by a few bf16 ulps (b_std 0.05: the output by 0.8 %; fixture keys `*_small`, the
+    reference's own unmerged run).  fp32 merge: the same function (<= 1e-5).  bf16 merge, as the device path stores it
+    (W + scale * B A rounded ONCE to bf16), evaluated in fp32 arithmetic: its distance to the reference's unmerged fp32
+    run is the rounding of the weights only -- no larger than what rounding the BASE weights costs the base model --
+    and far below the adapters' effect, i.e. the merged matrices still carry them."""
+    shape = sfa.WAN_REDUCED
+    eff = float(G["lora_effect_f32_small"])
+    assert 4e-3 < eff < 2e-2
+    small = sfa.synth_lora_state_dict(shape, int(G["rank"]), seed=int(G["lora_seed"]), targets=TARGETS, b_std=float(G["b_std_small"]))
+    sd16 = sfa.synth_state_dict(shape, seed=int(G["weights_seed"]))
+    cfg = wo.OracleConfig(dim=shape.dim, ffn_dim=shape.ffn_dim, num_heads=shape.num_heads, num_layers=shape.num_layers,
+                          text_dim=shape.text_dim)
+
+    def run(W):
+        kv, ca = wo.init_kv_cache(cfg, 1, 5 * FS, torch.float32), wo.init_crossattn_cache(cfg, 1, torch.float32)
+        return wo.forward_inference({k: v.float() for k, v in W.items()}, cfg, T(G["x1"]), T(G["t1"]), T(G["pe"]), kv, ca, 0)
+
+    merged32, loaded, _ = sfa.apply_lora_file({k: v.float() for k, v in sd16.items()}, small, shape, int(G["rank"]), float(G["alpha"]), TARGETS)
+    assert loaded == 10 * shape.num_layers and rel(run(merged32), T(G["y1_f32_small"])) < 1e-5
+    merged16, _, _ = sfa.apply_lora_file(sd16, small, shape, int(G["rank"]), float(G["alpha"]), TARGETS)
+    assert merged16["blocks.0.self_attn.q.weight"].dtype == torch.bfloat16
+    e_merge = rel(run(merged16), T(G["y1_f32_small"]))
+    e_base = rel(run(sd16), T(G["y1_f32_small"]))            # the base model: what ignoring the adapters would give
+    assert e_merge < 0.25 * eff and e_merge < 0.25 * e_base, (e_merge, e_base, eff)
+
+
 def test_merge_lora_in_state_dict_layout_equals_file_merge(G):
     """The layout `apply_lora` leaves in a checkpoint (`<linear>.base.weight` + lora_A / lora_B) merges to the same
     matrices as the file route."""
@@ -131,3 +173,15 @@ def test_hip_forward_with_lora_vs_reference(G, route, tmp_path):
     pipe._initialize_crossattn_cache(1, torch.bfloat16, "cuda:0")
     b1, _ = base(x1, {"prompt_embeds": pe}, T(G["t1"]).cuda(), pipe.kv_cache1, pipe.crossattn_cache, 0)
     assert rel(b1.permute(0, 2, 1, 3, 4), T(G["y1_f32"])) > 0.05
+    # small adapters (weights moved by a few bf16 ulps, output by 0.8 %): still honoured through the bf16 merge --
+    # within the tolerance of the reference's LoRA run AND closer to it than the adapter-free model is
+    small = sfa.synth_lora_state_dict(shape, int(G["rank"]), seed=int(G["lora_seed"]), targets=TARGETS, b_std=float(G["b_std_small"]))
+    if route == "lora_path":
+        path = str(tmp_path / "small.safetensors")
+        save_file({"diffusion_model." + k: v.contiguous() for k, v in small.items()}, path)
+        gs = sfa.WanDiffusionWrapper(state_dict=sd, lora_path=path, **kw)
+        pipe._initialize_kv_cache(1, torch.bfloat16, "cuda:0", cache_tokens=5 * FS)
+        pipe._initialize_crossattn_cache(1, torch.bfloat16, "cuda:0")
+        s1, _ = gs(x1, {"prompt_embeds": pe}, T(G["t1"]).cuda(), pipe.kv_cache1, pipe.crossattn_cache, 0)
+        e_lora, e_base = rel(s1.permute(0, 2, 1, 3, 4), T(G["y1_f32_small"])), rel(b1.permute(0, 2, 1, 3, 4), T(G["y1_f32_small"]))
+        assert e_lora < 2e-2 and e_lora < e_base, (e_lora, e_base, float(G["lora_effect_f32_small"]))
