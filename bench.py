@@ -478,16 +478,18 @@ def main():
     host_enqueue_stats(reset=True)
     if board is not None and world == 1:
         board.__enter__()
+    cpu0 = time.process_time()
     elapsed, local_elapsed, lats = grp.timed(lambda: pool.run(list(range(a.warmup, total)), one_step))
+    proc_cpu = time.process_time() - cpu0                       # CPU seconds of ALL threads of this rank (incl. the sampler's)
     if board is not None and world == 1:
         board.__exit__()
-    fw_calls, fw_secs, fw_threads = host_enqueue_stats()
+    fw_calls, fw_secs, fw_cpu, fw_threads = host_enqueue_stats()
     log(f"timed {a.steps} steps in {local_elapsed:.2f} s (max over ranks {elapsed:.2f} s)")
     lat = lats[-1]
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
     lat = lat[:1]                                               # the legs below work on ONE prompt's latents
     decoded = DECODED_PER_LATENT(a.frames)                      # per prompt
-    per_rank = grp.gather([a.steps * B * decoded, local_elapsed, fw_calls, fw_secs])
+    per_rank = grp.gather([a.steps * B * decoded, local_elapsed, fw_calls, fw_cpu, proc_cpu])
     grp.finish()                                                # last collective; rank 0's legs below run alone
     if rank != 0:
         return
@@ -531,15 +533,21 @@ def main():
         # host side of one rank (with no data-path collective only start-up skew and host contention can cost
         # scaling): wall time this rank's threads spent INSIDE sf_dit_forward (the C call that enqueues a pass's launches)
         "host_threads": a.streams,
-        "host_enqueue_ms_per_forward": 1e3 * fw_secs / max(1, fw_calls),
-        "host_enqueue_busy_cores": fw_secs / max(local_elapsed, 1e-9),
+        "host_enqueue_ms_per_forward": 1e3 * fw_cpu / max(1, fw_calls),
+        "host_enqueue_wall_ms_per_forward": 1e3 * fw_secs / max(1, fw_calls),
+        "host_busy_cores": proc_cpu / max(local_elapsed, 1e-9),
         "host_cores_available": usable_cores(),
-        "host_note": f"{fw_calls} forwards enqueued by {fw_threads} Python thread(s) in the timed region on rank 0; busy_cores = "
-                     "seconds inside sf_dit_forward / wall seconds (the C call releases the GIL; the Python around it is extra)",
+        "host_note": f"{fw_calls} forwards enqueued by {fw_threads} Python thread(s) in the timed region on rank 0. "
+                     "host_enqueue_ms_per_forward = CPU time of the calling thread inside sf_dit_forward (the C call that enqueues a "
+                     "pass's ~430 launches); _wall_ = wall time inside it, which includes waiting for room in the stream's launch "
+                     "queue because the host runs ahead of the GPU; host_busy_cores = CPU seconds of ALL threads of this rank's process "
+                     "(Python, torch, HIP runtime, the rocm-smi sampler thread) / wall seconds of the timed region: what one rank asks "
+                     "of the node's cores",
     }
     if world > 1:
         out["per_rank"] = {"frames": [r[0] for r in per_rank], "seconds": [r[1] for r in per_rank],
-                           "host_enqueue_ms_per_forward": [1e3 * r[3] / max(1.0, r[2]) for r in per_rank]}
+                           "host_enqueue_ms_per_forward": [1e3 * r[3] / max(1.0, r[2]) for r in per_rank],
+                           "host_busy_cores": [r[4] / max(r[1], 1e-9) for r in per_rank]}
     if board is not None and board.summary() is not None:
         out["board"] = board.summary()
         out["board"]["sampled_during"] = "the timed region" if world == 1 else "the warm-up steps (several ranks: nothing but the rollout runs in the timed region)"

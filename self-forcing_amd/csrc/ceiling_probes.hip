@@ -41,10 +41,19 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(const bf16x8* __restric
   out[blockIdx.x * 256 + tid] = s;
 }
 
+// 4 x 16 bytes per lane in flight per iteration (loads first, then stores), grid-stride over whole 16 KiB pieces per workgroup
 __global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n16) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
-    dst[i] = __builtin_nontemporal_load(src + i);
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  for (; i + 768 < n16; i += stride) {
+    const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256);
+    const u32x4 c = __builtin_nontemporal_load(src + i + 512), d = __builtin_nontemporal_load(src + i + 768);
+    __builtin_nontemporal_store(a, dst + i);
+    __builtin_nontemporal_store(b, dst + i + 256);
+    __builtin_nontemporal_store(c, dst + i + 512);
+    __builtin_nontemporal_store(d, dst + i + 768);
+  }
+  for (; i < n16; i += 256) dst[i] = src[i];     // this lane's share of the ragged last piece (at most 3 elements)
 }
 
 extern "C" int sf_probe_mfma(int shape, int iters, int workgroups, const void* operands, float* sink, double* flops_out, void* stream) {
@@ -65,7 +74,7 @@ extern "C" int sf_probe_mfma(int shape, int iters, int workgroups, const void* o
 extern "C" int sf_probe_copy(const void* src, void* dst, size_t bytes, void* stream) {
   SF_CHECK(src && dst && bytes >= 16 && bytes % 16 == 0, "sf_probe_copy: null pointer or byte count %zu not a multiple of 16", bytes);
   SF_CHECK(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "sf_probe_copy: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, (int64_t)(bytes / 16));
+  hipLaunchKernelGGL(probe_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, (int64_t)(bytes / 16));
   SF_HIP_LAUNCH_CHECK("sf_probe_copy");
   return 0;
 }

@@ -201,19 +201,22 @@ def _(x0, eps, timestep, sigmas, timesteps):
 _TABLES: Dict[int, tuple] = {}
 
 # Host time spent INSIDE sf_dit_forward (the C call that enqueues the ~430 launches of a pass), per calling thread:
-# {thread id: [calls, seconds]}.  bench.py reports it as host_enqueue_ms_per_forward -- with one process per GPU and
-# `streams` enqueuing threads per process, 8 ranks x that many threads must fit the node's cores.
+# {thread id: [calls, wall seconds, CPU seconds of the thread]}.  Wall time includes waiting for room in the stream's
+# launch queue when the host runs ahead of the GPU (it does: a pass is ~25-50 ms of GPU work); the thread's CPU time is
+# what the call really costs the host.  bench.py reports both -- with one process per GPU and `streams` enqueuing
+# threads per process, 8 ranks x that many threads must fit the node's cores.
 HOST_ENQUEUE: Dict[int, list] = {}
 
 
 def host_enqueue_stats(reset: bool = False):
-    """(forwards, seconds, threads) summed over the threads that called dit_forward since the last reset."""
+    """(forwards, wall seconds, CPU seconds, threads) summed over the threads that called dit_forward since the last reset."""
     calls = sum(v[0] for v in HOST_ENQUEUE.values())
-    secs = sum(v[1] for v in HOST_ENQUEUE.values())
+    wall = sum(v[1] for v in HOST_ENQUEUE.values())
+    cpu = sum(v[2] for v in HOST_ENQUEUE.values())
     n = sum(1 for v in HOST_ENQUEUE.values() if v[0])
     if reset:
         HOST_ENQUEUE.clear()
-    return calls, secs, n
+    return calls, wall, cpu, n
 
 
 def _pointer_tables(handle: int, k: Sequence[Tensor], v: Sequence[Tensor], ck: Sequence[Tensor], cv: Sequence[Tensor],
@@ -315,12 +318,13 @@ def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Opti
             raise ValueError(f"dit_forward: kv_index must be a contiguous CUDA int64 [{L}, 2] tensor")
         a.kv_index_out, a.global_end = kv_index.data_ptr(), global_end
     fn, st = _lib.lib().sf_dit_forward, _stream(noisy)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     rc = fn(C.byref(m.cmodel), C.byref(a), st)
-    dt = time.perf_counter() - t0
-    rec = HOST_ENQUEUE.setdefault(threading.get_ident(), [0, 0.0])
+    dt, dc = time.perf_counter() - t0, time.thread_time() - c0
+    rec = HOST_ENQUEUE.setdefault(threading.get_ident(), [0, 0.0, 0.0])
     rec[0] += 1
     rec[1] += dt
+    rec[2] += dc
     _lib.check(rc, "sf_dit_forward")
     return flow, x0
 

@@ -406,12 +406,13 @@ def test_add_condition_identity_projection_on_dim_5120_models():
     # a dim-1536 model WITHOUT pose_proj weights cannot take pose tokens: refused, not guessed
     small = sfa.WanDiffusionWrapper(shape=sfa.WAN_REDUCED, state_dict=sfa.synth_state_dict(sfa.WAN_REDUCED, seed=0), timestep_shift=5.0,
                                     is_causal=True, device=DEV)
-    p2 = sfa.CausalInferencePipeline(args, DEV, generator=small, text_encoder=sfa.FixedTextEncoder(pe.to(DEV)), vae=sfa.IdentityVAE())
+    pe2 = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    p2 = sfa.CausalInferencePipeline(args, DEV, generator=small, text_encoder=sfa.FixedTextEncoder(pe2), vae=sfa.IdentityVAE())
     p2.frame_seq_length = FS
     p2._initialize_kv_cache(1, torch.bfloat16, DEV, cache_tokens=2 * FS)
     p2._initialize_crossattn_cache(1, torch.bfloat16, DEV)
     with pytest.raises(ValueError, match="needs pose_proj weights"):
-        small(x.to(DEV), {"prompt_embeds": pe.to(DEV), "add_condition": cond.to(DEV)}, t.to(DEV), p2.kv_cache1, p2.crossattn_cache, 0)
+        small(x.to(DEV), {"prompt_embeds": pe2, "add_condition": cond.to(DEV)}, t.to(DEV), p2.kv_cache1, p2.crossattn_cache, 0)
 
 
 def _conv_corunner(g):
