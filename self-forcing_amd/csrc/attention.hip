@@ -709,7 +709,9 @@ __global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
     for (int qb = 0; qb < 2; ++qb) {
       const int qrow = qt * QT64 + wave * 64 + qb * 32 + r32;
       const unsigned long long qa = (unsigned long long)(qbase + (long)min(qrow, p.Lq - 1) * p.q_stride + 8 * hh);
-      const unsigned long long oa = (unsigned long long)(obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 4 * hh);
+      // (the epilogue regroups a lane pair's two 8-byte halves into 16-byte stores: lane l writes the even 16-byte group,
+      // lane l + 32 the odd one)
+      const unsigned long long oa = (unsigned long long)(obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 8 * hh);
       prm[20 + 2 * qb] = (unsigned)qa; prm[21 + 2 * qb] = (unsigned)(qa >> 32);
       prm[24 + 2 * qb] = (unsigned)oa; prm[25 + 2 * qb] = (unsigned)(oa >> 32);
       prm[29 + qb] = qrow < p.Lq ? 1u : 0u;
@@ -772,9 +774,12 @@ extern "C" int sf_attention_ex(const void* q, const void* k, const void* v, void
   // for every shape; the explicit values exist for tests and A/B timing.
   const long nwg64 = (long)((Lq + QT64 - 1) / QT64) * H * B;
   const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
+  // (the 64-row kernel stores 16 bytes per lane: it needs 16-byte aligned output rows)
+  const bool out16 = ((uintptr_t)out % 16 == 0) && o_stride % 8 == 0 && o_bstride % 8 == 0;
   if (structure == SF_ATTN_AUTO)
-    structure = (nwg64 >= 192 && Lk > 1024) ? SF_ATTN_R64 : nwg8 >= 192 ? SF_ATTN_W8 : SF_ATTN_W4;
+    structure = (nwg64 >= 192 && Lk > 1024 && out16) ? SF_ATTN_R64 : nwg8 >= 192 ? SF_ATTN_W8 : SF_ATTN_W4;
   if (structure == SF_ATTN_R64) {
+    SF_CHECK(out16, "sf_attention: the r64 structure needs 16-byte aligned output rows (out %% 16, o_stride %% 8, o_bstride %% 8)");
     p.q_tiles = (Lq + QT64 - 1) / QT64;
     static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent; no other state is kept)
     if (!attr) {

@@ -310,8 +310,12 @@ def test_decode_frames_rejects_bad_window_arguments():
     out = torch.empty(12, 3, 64, 64, dtype=torch.float32, device=DEV)
     K = dec.window_frames
     op = torch.ops.sf_hip.vae_decode_frames
-    with pytest.raises(RuntimeError, match="decoded alone"):
+    with pytest.raises((RuntimeError, ValueError), match="decoded alone"):
         op(dec._handle, state, scratch, z[:2], out, 8, 8, K, 0, 0, 0)            # the first chunk with a second frame
+    with pytest.raises(ValueError, match="out holds"):
+        op(dec._handle, state, scratch, z[:2], out[:7], 8, 8, K, 1, 1, 1)        # 2 latent frames = 8 pixel frames
+    with pytest.raises(ValueError, match="uint8"):
+        op(dec._handle, state.view(torch.int16), scratch, z[:1], out, 8, 8, K, 1, 1, 1)
     with pytest.raises(RuntimeError, match="n_frames"):
         op(dec._handle, state, scratch, z, out, 8, 8, K, 1, 1, 1)                # 3 frames > window_frames - 1
     with pytest.raises(RuntimeError, match="does not fit"):

@@ -44,6 +44,9 @@ ABL = set()          # timing-only ablations: nosoftmax, nolds, nomfma, nodma, n
 if "--abl" in sys.argv:
     ABL = set(sys.argv[sys.argv.index("--abl") + 1].split(","))
 
+ALIGN = int(sys.argv[sys.argv.index("--align") + 1]) if "--align" in sys.argv else 6    # log2 bytes; 0 = none
+PAD = int(sys.argv[sys.argv.index("--pad") + 1]) if "--pad" in sys.argv else 0          # extra 4-byte s_nops behind it
+
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "self-forcing_amd", "csrc",
                    "attention_r64_asm.inc")
 
@@ -443,6 +446,10 @@ def main():
         e(f"s_mov_b32 s{sr}, {i * 16384}")
     for i, sr in enumerate((VS_CUR, VS_N1, VS_DMA)):
         e(f"s_mov_b32 s{sr}, {V_BASE + i * 16384}")
+    e("; ---- Q^T fragments: requested FIRST (they need no LDS), so that the LDS zeroing and the first K / V requests run under them")
+    for qb in range(2):
+        for s in range(8):
+            e(f"global_load_dwordx4 {vr(S[0] + (qb * 8 + s) * 4, 4)}, {vr(QP[qb], 2)}, off offset:{s * 32}")
     e("; ---- zero the seven LDS slots (rows past Lk are never fetched; 0 * stale NaN would poison P.V)")
     for i in range(4):
         e(f"v_mov_b32 {vr(TMP + i)}, 0")
@@ -454,7 +461,7 @@ def main():
         e(f"ds_write_b128 {vr(TMP + 4 + i // 16)}, {vr(TMP, 4)} offset:{(i % 16) * 4096}")
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")
-    e("; ---- first tiles: K(0), K(1), K(2), V(0), V(1) (tile indices clamped to the last tile)")
+    e("; ---- first tiles: K(0), V(0), K(1), V(1), K(2) (tile indices clamped to the last tile): 20 requests per wave, in this order")
     e(f"s_mov_b32 s{SOFFK}, 0")
     dma(K_SRD, SOFFK, KS_CUR, True)
     dma(V_SRD, SOFFK, VS_CUR, True)
@@ -463,13 +470,10 @@ def main():
     dma(V_SRD, SOFFK, VS_N1, True)
     clamp_tile(SOFFK, 2)
     dma(K_SRD, SOFFK, KS_N2, True)
-    e("; ---- Q^T fragments, scaled by c, -> AGPRs; O^T = 0")
-    for qb in range(2):
-        for s in range(8):
-            e(f"global_load_dwordx4 {vr(S[0] + (qb * 8 + s) * 4, 4)}, {vr(QP[qb], 2)}, off offset:{s * 32}")
+    e("; ---- O^T = 0; Q^T scaled by c -> AGPRs as soon as Q has landed (the 20 tile requests stay in flight behind it)")
     for i in range(128):
         e(f"v_accvgpr_write_b32 {ar(i)}, 0")
-    e("s_waitcnt vmcnt(0)")
+    e("s_waitcnt vmcnt(20)")
     for i in range(64):
         x = S[0] + i
         e(f"v_lshlrev_b32 {vr(TMP)}, 16, {vr(x)}")
@@ -478,6 +482,8 @@ def main():
         e(f"v_cvt_pk_bf16_f32 {vr(x)}, {vr(TMP)}, {vr(TMP + 1)}")
         e(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(x)}")
     e("s_nop 4")
+    e("; ---- K(0) is all the first product needs: wait for this wave's four pieces of it, then for the other waves'")
+    e("s_waitcnt vmcnt(16)")
     e("s_barrier")
     for _, t in set_kcur(KS_CUR):
         e(t)
@@ -506,6 +512,12 @@ def main():
         e(f"v_mov_b32 {vr(MX[qb])}, 0")
     e("s_nop 4")
     loop, last_l, pen_l = ".Lr64_loop%=", ".Lr64_last%=", ".Lr64_penult%="
+    # the loop head's placement is pinned (a hand-written stream is sensitive to where it sits relative to the fetch
+    # granule: MI355X_MICROARCH.md, 'Code-placement sensitivity'), so edits to the prologue do not move the loop body
+    if ALIGN:
+        e(f".p2align {ALIGN}")
+        for _ in range(PAD):
+            e("s_nop 0")
     e(f"{loop}:")
     e(f"s_cmp_eq_u32 s{ST}, s{NTM1}")
     e(f"s_cbranch_scc1 {last_l}")
@@ -533,19 +545,30 @@ def main():
         e("s_nop 1")
         e(f"v_cmp_ne_u32 vcc, 0, {vr(VALID[qb])}")
         e(f"s_and_saveexec_b64 s[{SEXEC}:{SEXEC + 1}], vcc")
+        # The lane pair (l, l + 32) holds the two 8-byte halves of 16 contiguous output bytes (d = 8 g + 4 hh + 0..3).
+        # One v_permlane32_swap per register pair regroups them so that lane l stores the whole 16 bytes of the even
+        # group and lane l + 32 those of the odd group: 2 x global_store_dwordx4 per head-dim block instead of 4 x
+        # dwordx2 (the store tail is issue-bound).  Every block converts into registers of its own (qb 0: the S[1]
+        # region, qb 1: MINIT, dead by now), so no store has to be waited for before the next block's values are formed.
+        obuf = S[1] if qb == 0 else MINIT[0]
         for db in range(4):
+            o8 = obuf + 8 * db
             for i in range(16):
                 e(f"v_accvgpr_read_b32 {vr(S[0] + i)}, {ar(A_O(qb, db) + i)}")
             e("s_nop 1")
             for i in range(16):
                 e(f"v_mul_f32 {vr(S[0] + i)}, {vr(S[0] + i)}, {vr(DLT[0])}")
             for i in range(8):
-                e(f"v_cvt_pk_bf16_f32 {vr(S[1] + i)}, {vr(S[0] + 2 * i)}, {vr(S[0] + 2 * i + 1)}")
-            for rg in range(4):
-                if "nostore" in ABL and (db or rg):
+                e(f"v_cvt_pk_bf16_f32 {vr(o8 + i)}, {vr(S[0] + 2 * i)}, {vr(S[0] + 2 * i + 1)}")
+            e("s_nop 1")
+            for pr in range(2):       # groups (2 pr, 2 pr + 1): registers o8 + 4 pr + {0, 1 | 2, 3}
+                for j in range(2):
+                    e(f"v_permlane32_swap_b32 {vr(o8 + 4 * pr + j)}, {vr(o8 + 4 * pr + 2 + j)}")
+            e("s_nop 1")
+            for pr in range(2):
+                if "nostore" in ABL and (db or pr):
                     continue
-                e(f"global_store_dwordx2 {vr(OP[qb], 2)}, {vr(S[1] + 2 * rg, 2)}, off offset:{db * 64 + rg * 16}")
-            e("s_waitcnt vmcnt(0)")
+                e(f"global_store_dwordx4 {vr(OP[qb], 2)}, {vr(o8 + 4 * pr, 4)}, off offset:{db * 64 + pr * 32}")
         e(f"s_mov_b64 exec, s[{SEXEC}:{SEXEC + 1}]")
     end_l = ".Lr64_end%="
     e(f"s_branch {end_l}")
