@@ -340,6 +340,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(GemmP p) {
 // (lgkmcnt(0)) before the barrier that ends its interval, so the regions are free when the requests above are issued
 // (A(t+1) goes to the OTHER buffer, last read during tile t-1).  Read-after-write: tile t+1's first reads come after
 // the barrier behind the vmcnt(4) of phase (t, 3), executed by every wave: everything but B(t+2) has landed.
+//
+// Slot-by-slot (global barrier intervals I; group 0's load segment of (t, j) is I = 8t + 2j, its cluster 8t + 2j + 1,
+// group 1 runs one interval later; group g reads only A half g, column group wc reads only its 64 rows of B):
+//   A half 0 of buffer (t+1)&1: last read by group 0 at I = 8t - 4 (tile t-1, phase 2), rewritten by requests issued at
+//     I = 8t (group 0) / 8t + 1 (group 1); first read again at I = 8t + 8, behind every wave's vmcnt(4) (I = 8t + 6 / 8t + 7)
+//     and the barrier that ends I = 8t + 7.  A half 1: the same, one phase later (read until 8t - 3, rewritten from 8t + 2).
+//   B halves of buffer t&1: last read at I = 8t + 3 (group 1, phase 1), rewritten from I = 8t + 4 / 8t + 6; first read at
+//     I = 8t + 16, behind the vmcnt(4) of tile t + 1 (whose four youngest requests are B(t+3)).
+//   Epilogue scratch (wave w: [w, w + 1) x MT x 2 KiB of the stages): entered only after the last tile's vmcnt(0)
+//     (executed by every wave before a barrier that precedes every epilogue) -- no request is in flight, none is issued
+//     afterwards, every fragment read was retired >= 3 intervals earlier.
+//
+// THE RACE OF THE PERSISTENT EXPERIMENT (git ba94dce, removed in 77df59c; analysed in round 3 from the diff).  That
+// kernel continued the pipeline across OUTPUT tiles and ran each tile's epilogue without a workgroup barrier, group 0's
+// four waves transposing through 8 KiB of scratch each inside buffer 1's A region (dead between the last k-tile's reads
+// and the next output tile's A(1) requests).  The argument written there -- "A(1) is requested by each wave after its own
+// epilogue, and by the other group after theirs" -- covers a wave's OWN scratch only: an LDS-DMA piece of A half 0 is
+// 1 KiB at offset w x 1 KiB (+ 8 KiB) for EVERY wave w, i.e. the four waves' first requests of the next tile (issued in
+// the same barrier interval as the epilogue, right behind their own, with no barrier in between) land in [0, 4 K) and
+// [8 K, 12 K): the scratch of waves 0 and 1 -- so wave 2 or 3 (or wave 1 into wave 0's, wave 0 into wave 1's) can
+// overwrite rows a sibling is still transposing (an epilogue's length varies with its residual / gate loads).  Group 1's requests were safe (they follow the
+// barrier group 0 reaches only after all four epilogues); the intra-group order was the missing wait.  It showed on
+// the one test shape with several tiles per workgroup AND long epilogues (10800 x 5120 x 5120: 860 tiles on 256
+// workgroups), rarely.  A fix would have been a group-local rendezvous (LDS counter of the four waves) between the
+// epilogues and the first A(1) request, or per-wave scratch outside every LDS-DMA target (4 KiB x 8 in the 32 KiB above
+// the stages, four passes per sub-tile).  The kernels shipped here have no such window: their scratch is touched only
+// after the last request has landed everywhere and nothing is requested after it (the third bullet above).
 constexpr int PP_THREADS = 512;
 
 template <int MT>   // M tiles of 16 rows per wave: 8 (256-row workgroup tile), 7 (224), 6 (192)

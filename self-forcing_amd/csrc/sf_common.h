@@ -37,15 +37,32 @@ extern "C" void sf_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
+// Wave-wide reductions by DPP (six VALU instructions with the lane movement built in, then one v_readlane broadcast)
+// instead of six __shfl_xor steps: hipcc lowers those to ds_bpermute_b32 -- a round trip through the LDS crossbar each,
+// ~100 cycles of latency, six of them dependent per reduction -- which is most of what a one-pass norm kernel does
+// between its loads and its stores.  All 64 lanes must be active.  (The order of the fp32 additions differs from the
+// butterfly's; every caller rounds the result into bf16 outputs.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float sf_dpp(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += sf_dpp<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
+  v += sf_dpp<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
+  v += sf_dpp<0x141, 0xF>(0.f, v);    // row_half_mirror
+  v += sf_dpp<0x140, 0xF>(0.f, v);    // row_mirror: every lane of a row of 16 holds that row's sum
+  v += sf_dpp<0x142, 0xA>(0.f, v);    // row_bcast15: rows 1 and 3 add lane 15 of the row before
+  v += sf_dpp<0x143, 0xC>(0.f, v);    // row_bcast31: rows 2 and 3 add lane 31 -> lanes 48..63 hold the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, sf_dpp<0xB1, 0xF>(v, v));
+  v = fmaxf(v, sf_dpp<0x4E, 0xF>(v, v));
+  v = fmaxf(v, sf_dpp<0x141, 0xF>(v, v));
+  v = fmaxf(v, sf_dpp<0x140, 0xF>(v, v));
+  v = fmaxf(v, sf_dpp<0x142, 0xA>(v, v));
+  v = fmaxf(v, sf_dpp<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // tanh-approximated GELU, nn.GELU(approximate='tanh'):  0.5 x (1 + tanh(u)), u = k0 (x + k1 x^3)

@@ -75,6 +75,97 @@ __global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const bf16_t* 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident form for the rollout's shapes (M <= 8 rows, K <= 1536): the kernel is a pure weight stream (28 MB for
+// time_projection at 1.3B), so the ONLY thing that matters is how early and how many bytes are in flight:
+//   * a wave requests ALL its weights first -- 4 output columns x KS steps x 16 bytes per lane (12 loads, 48 VGPRs at
+//     K = 1536); with 9 waves per CU that is 110 KB in flight per CU from the first cycle on.  The LDS form above staged
+//     the activations first (scalar loads + SiLU + a workgroup barrier: ~2 us before the first weight byte was asked for);
+//   * the M activation rows are 9 KB shared by every wave: read straight from L2 into registers (packed bf16, activation
+//     applied and rounded to bf16 exactly as the LDS form stores them), no LDS, no barrier;
+//   * products by v_dot2c_f32_bf16 (two bf16 products + fp32 accumulate per instruction: a quarter of the VALU work of
+//     convert + FMA), wave reduction by six DPP adds per value (sf_common.h) instead of six ds_bpermute round trips.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int SLR_THREADS = 512;   // 8 waves x 4 columns = 32 output columns per workgroup: N / 32 workgroups (288 for 6 x 1536)
+
+template <int MB, int KS>
+__global__ __launch_bounds__(SLR_THREADS) void small_linear_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                       const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                       int N, int K, int act_in, int act_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [MB][K] bf16, only when act_in != 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = (blockIdx.x * (SLR_THREADS / 64) + wave) * SL_NPW;
+  // 1. every weight byte this wave needs, requested before anything else
+  bf16x8 wv[SL_NPW][KS];
+#pragma unroll
+  for (int c = 0; c < SL_NPW; ++c) {
+    const bf16_t* wrow = w + (long)min(n0 + c, N - 1) * K;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = s * 512 + lane * 8;
+      wv[c][s] = (k < K && n0 < N) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + k)) : bf16x8{};
+    }
+  }
+  // 2. the activation rows.  With an input activation (SiLU in front of time_projection) the workgroup applies it ONCE,
+  // cooperatively, and shares the rounded bf16 values through LDS: done per wave it was ~20 VALU instructions on 72
+  // elements per lane -- more time than the weight stream takes.  Without one the rows come straight from L2.
+  bf16x8 xv[MB][KS];
+  if (act_in != 0) {
+    bf16x8* xs = reinterpret_cast<bf16x8*>(smem);
+    const int chunks = MB * K / 8;
+    for (int i = tid; i < chunks; i += SLR_THREADS) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (long)i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = (bf16_t)apply_act((float)t[j], act_in);
+      xs[i] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = s * 512 + lane * 8;
+        xv[m][s] = k < K ? xs[(m * K + k) / 8] : bf16x8{};
+      }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = s * 512 + lane * 8;
+        xv[m][s] = k < K ? *reinterpret_cast<const bf16x8*>(x + (long)m * K + k) : bf16x8{};
+      }
+  }
+  if (n0 >= N) return;
+  // 3. dot products (fp32 accumulation), 4. wave reduction, lane 0 writes
+  float acc[SL_NPW][MB];
+#pragma unroll
+  for (int c = 0; c < SL_NPW; ++c)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x2_t xa = {xv[m][s][2 * j], xv[m][s][2 * j + 1]}, wa = {wv[c][s][2 * j], wv[c][s][2 * j + 1]};
+          a = __builtin_amdgcn_fdot2_f32_bf16(xa, wa, a, false);
+        }
+      acc[c][m] = wave_sum(a);       // (DPP adds + one readlane: sf_common.h)
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < SL_NPW; ++c) {
+      const int n = n0 + c;
+      if (n >= N) continue;
+      const float b = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) out[(long)m * N + n] = (bf16_t)apply_act(acc[c][m] + b, act_out);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sf_small_linear(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
@@ -84,6 +175,22 @@ extern "C" int sf_small_linear(const void* x, const void* w, const void* bias, v
   SF_CHECK((size_t)SL_MB_MAX * K * 2 <= 160 * 1024, "sf_small_linear: K=%d too large for the LDS activation stage", K);
   SF_CHECK(act_in >= 0 && act_in <= 2 && act_out >= 0 && act_out <= 2, "sf_small_linear: bad activation code");
   const int waves_needed = (N + SL_NPW - 1) / SL_NPW;
+  const int ks = (K + 511) / 512;
+  if (M <= 8 && (ks == 1 || ks == 3)) {   // the rollout's shapes: K = freq_dim 256 and K = dim 1536, M = batch x groups
+    const dim3 grid((waves_needed + SLR_THREADS / 64 - 1) / (SLR_THREADS / 64)), block(SLR_THREADS);
+    const size_t lds = act_in != 0 ? (size_t)M * K * 2 : 0;
+#define SF_SLR(R, S)                                                                                                               \
+  hipLaunchKernelGGL((small_linear_reg_kernel<R, S>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, \
+                     (const bf16_t*)bias, (bf16_t*)out, N, K, act_in, act_out)
+#define SF_SLR_M(S)                                                                                                                   \
+  switch (M) { case 1: SF_SLR(1, S); break; case 2: SF_SLR(2, S); break; case 3: SF_SLR(3, S); break; case 4: SF_SLR(4, S); break; \
+               case 5: SF_SLR(5, S); break; case 6: SF_SLR(6, S); break; case 7: SF_SLR(7, S); break; default: SF_SLR(8, S); break; }
+    if (ks == 1) { SF_SLR_M(1) } else { SF_SLR_M(3) }
+#undef SF_SLR_M
+#undef SF_SLR
+    SF_HIP_LAUNCH_CHECK("sf_small_linear");
+    return 0;
+  }
   const int blocks = min(1024, (waves_needed + 3) / 4);
   for (int m0 = 0; m0 < M; m0 += SL_MB_MAX) {
     const int mc = min(SL_MB_MAX, M - m0);

@@ -90,6 +90,31 @@ class WanDiffusionWrapper(torch.nn.Module):
         self.model = CausalWanModel(shape, state_dict, device, self.scheduler.sigmas, self.scheduler.timesteps)
         self.seq_len = 32760
         self._evict_scratch: Optional[Tensor] = None
+        self._init_throttle()
+
+    # --- host-side pacing ---------------------------------------------------------------------
+    # One forward is 25-50 ms of GPU work and ~2 ms of host work, so the calling thread runs far ahead of the GPU until the
+    # stream's launch queue is full -- and then SPINS inside the HIP runtime for room (measured: the thread's CPU time inside
+    # sf_dit_forward equals its wall time, one busy core per rollout thread).  With one process per GPU and two rollout
+    # threads per process that is 16 spinning cores on an 8-GPU node for nothing.  Instead the wrapper keeps at most
+    # `max_inflight_forwards` passes enqueued (per wrapper = per stream) and waits for the oldest one on an event created
+    # with blocking sync: the thread sleeps in the kernel instead of spinning.  Two passes in flight keep >= 25 ms of work
+    # queued, so the GPU never waits for the host.  0 disables the pacing.
+    max_inflight_forwards = 2
+
+    def _init_throttle(self) -> None:
+        import collections
+        self._inflight = collections.deque()
+
+    def _pace(self, device) -> None:
+        n = self.max_inflight_forwards
+        if n <= 0 or torch.compiler.is_compiling():
+            return
+        ev = torch.cuda.Event(blocking=True)
+        ev.record(torch.cuda.current_stream(device))
+        self._inflight.append(ev)
+        while len(self._inflight) > n:
+            self._inflight.popleft().synchronize()
 
     def share(self) -> "WanDiffusionWrapper":
         """A second wrapper over the SAME device weights (own pointer tables / scratch), for a second
@@ -101,6 +126,7 @@ class WanDiffusionWrapper(torch.nn.Module):
         other.model = self.model
         other.seq_len = self.seq_len
         other._evict_scratch = None
+        other._init_throttle()
         return other
 
     # --- reference API ------------------------------------------------------------------------
@@ -235,4 +261,5 @@ class WanDiffusionWrapper(torch.nn.Module):
             for c in crossattn_cache:
                 c["is_init"] = True
         self._write_indices(kv_cache, plan.global_end, plan.local_end, done_by_kernel=index_buf is not None)
+        self._pace(mdl.device)
         return flow, x0
