@@ -499,7 +499,7 @@ def main():
     flops_exec = B * rollout_flops(shape, a.frames, nfpb, len(step_list), fs, window, executed=True)
     # one rollout ALONE on the GPU (one stream): the same step, nothing in flight beside it
     one = None
-    if a.streams > 1 or B > 1:
+    if (a.streams > 1 or B > 1) and not a.rollout_only:
         def single(i):
             noise = torch.randn([1, a.frames, 16, LAT_H, LAT_W], device=dev, dtype=torch.bfloat16)
             return pool.pipes[0].inference(noise, [prompts[i]], return_latents=True)[1]

@@ -87,24 +87,36 @@ __global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const bf16_t* 
 //     convert + FMA), wave reduction by six DPP adds per value (sf_common.h) instead of six ds_bpermute round trips.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int SLR_THREADS = 512;   // 8 waves x 4 columns = 32 output columns per workgroup: N / 32 workgroups (288 for 6 x 1536)
+constexpr int SLR_MAX_THREADS = 640;   // up to 10 waves x 4 columns per workgroup; the host picks the wave count so that the
+                                       // grid is ONE workgroup per CU where it can (6 x 1536 columns: 9 waves x 256 workgroups)
 
-template <int MB, int KS>
-__global__ __launch_bounds__(SLR_THREADS) void small_linear_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                                       const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
-                                                                       int N, int K, int act_in, int act_out) {
+template <int MB, int KS, int act_in>   // act_in compile-time: straight-line code, so the waits are counted (vmcnt(12)), not drained
+__global__ __launch_bounds__(SLR_MAX_THREADS) void small_linear_reg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                           const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                           int N, int K, int act_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];     // [MB][K] bf16, only when act_in != 0
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = (blockIdx.x * (SLR_THREADS / 64) + wave) * SL_NPW;
-  // 1. every weight byte this wave needs, requested before anything else
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int n0 = (blockIdx.x * (nthreads >> 6) + wave) * SL_NPW;
+  // 0. with an input activation: this thread's share of the activation rows, requested BEFORE the weights -- vmcnt
+  // retires in order, so the (L2-resident) rows can be waited for while the twelve weight loads behind them are in flight
+  constexpr int XCH = (MB * KS * 64 + 255) / 256;                 // chunks of 8 per thread at >= 256 threads
+  bf16x8 xraw[XCH];
+  const int chunks = MB * K / 8;
+  if (act_in != 0) {
+#pragma unroll
+    for (int i = 0; i < XCH; ++i)      // (addresses clamped, never predicated: branch-free code keeps the waits counted)
+      xraw[i] = *reinterpret_cast<const bf16x8*>(x + (long)min(tid + i * nthreads, chunks - 1) * 8);
+    __builtin_amdgcn_sched_barrier(0);   // (the rows' requests stay in FRONT of the weights': vmcnt retires in order)
+  }
+  // 1. every weight byte this wave needs
   bf16x8 wv[SL_NPW][KS];
 #pragma unroll
   for (int c = 0; c < SL_NPW; ++c) {
     const bf16_t* wrow = w + (long)min(n0 + c, N - 1) * K;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int k = s * 512 + lane * 8;
-      wv[c][s] = (k < K && n0 < N) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + k)) : bf16x8{};
+      const int k = min(s * 512 + lane * 8, K - 8);      // (lanes past K re-read the last chunk; their activations are zero)
+      wv[c][s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + k));
     }
   }
   // 2. the activation rows.  With an input activation (SiLU in front of time_projection) the workgroup applies it ONCE,
@@ -113,20 +125,22 @@ __global__ __launch_bounds__(SLR_THREADS) void small_linear_reg_kernel(const bf1
   bf16x8 xv[MB][KS];
   if (act_in != 0) {
     bf16x8* xs = reinterpret_cast<bf16x8*>(smem);
-    const int chunks = MB * K / 8;
-    for (int i = tid; i < chunks; i += SLR_THREADS) {
-      bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (long)i * 8);
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      bf16x8 t = xraw[i];
 #pragma unroll
       for (int j = 0; j < 8; ++j) t[j] = (bf16_t)apply_act((float)t[j], act_in);
-      xs[i] = t;
+      xs[tid + i * nthreads] = t;      // (the LDS stage is sized XCH x nthreads chunks: slots past `chunks` are padding)
     }
-    __syncthreads();
+    // raw barrier: __syncthreads() carries a fence that drains vmcnt -- the weight loads must stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int k = s * 512 + lane * 8;
-        xv[m][s] = k < K ? xs[(m * K + k) / 8] : bf16x8{};
+        const bf16x8 t = xs[(m * K + min(k, K - 8)) / 8];
+        xv[m][s] = k < K ? t : bf16x8{};
       }
   } else {
 #pragma unroll
@@ -134,11 +148,13 @@ __global__ __launch_bounds__(SLR_THREADS) void small_linear_reg_kernel(const bf1
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int k = s * 512 + lane * 8;
-        xv[m][s] = k < K ? *reinterpret_cast<const bf16x8*>(x + (long)m * K + k) : bf16x8{};
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (long)m * K + min(k, K - 8));
+        xv[m][s] = k < K ? t : bf16x8{};
       }
   }
-  if (n0 >= N) return;
-  // 3. dot products (fp32 accumulation), 4. wave reduction, lane 0 writes
+  __builtin_amdgcn_sched_barrier(0);   // (every load above stays above: nothing below may be scheduled in front of a request)
+  // 3. dot products (fp32 accumulation), 4. wave reduction, lane 0 writes.  Waves past N (last workgroup only) run on
+  // clamped rows and store nothing: an early return would let the compiler sink the weight loads behind it.
   float acc[SL_NPW][MB];
 #pragma unroll
   for (int c = 0; c < SL_NPW; ++c)
@@ -176,12 +192,21 @@ extern "C" int sf_small_linear(const void* x, const void* w, const void* bias, v
   SF_CHECK(act_in >= 0 && act_in <= 2 && act_out >= 0 && act_out <= 2, "sf_small_linear: bad activation code");
   const int waves_needed = (N + SL_NPW - 1) / SL_NPW;
   const int ks = (K + 511) / 512;
-  if (M <= 8 && (ks == 1 || ks == 3)) {   // the rollout's shapes: K = freq_dim 256 and K = dim 1536, M = batch x groups
-    const dim3 grid((waves_needed + SLR_THREADS / 64 - 1) / (SLR_THREADS / 64)), block(SLR_THREADS);
-    const size_t lds = act_in != 0 ? (size_t)M * K * 2 : 0;
-#define SF_SLR(R, S)                                                                                                               \
-  hipLaunchKernelGGL((small_linear_reg_kernel<R, S>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, \
-                     (const bf16_t*)bias, (bf16_t*)out, N, K, act_in, act_out)
+  if (M <= 8 && (ks == 1 || ks == 3) && act_in <= 1) {   // the rollout's shapes: K = freq_dim 256 and K = dim 1536, M = batch x groups
+    // waves per workgroup: enough that 256 workgroups cover N (one per CU, no second round on a few CUs), 4 .. 10
+    const int wpb = min(SLR_MAX_THREADS / 64, max(4, (waves_needed + 255) / 256));
+    const dim3 grid((waves_needed + wpb - 1) / wpb), block(64 * wpb);
+    const int xch = (M * ks * 64 + 255) / 256;                               // = XCH of the instantiation
+    const size_t lds = act_in != 0 ? (size_t)xch * 64 * wpb * 16 : 0;        // chunks of 16 bytes, padded to whole passes
+#define SF_SLR(R, S)                                                                                                                  \
+  do {                                                                                                                                \
+    if (act_in == 0)                                                                                                                  \
+      hipLaunchKernelGGL((small_linear_reg_kernel<R, S, 0>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, \
+                         (const bf16_t*)bias, (bf16_t*)out, N, K, act_out);                                                           \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((small_linear_reg_kernel<R, S, 1>), grid, block, lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, \
+                         (const bf16_t*)bias, (bf16_t*)out, N, K, act_out);                                                           \
+  } while (0)
 #define SF_SLR_M(S)                                                                                                                   \
   switch (M) { case 1: SF_SLR(1, S); break; case 2: SF_SLR(2, S); break; case 3: SF_SLR(3, S); break; case 4: SF_SLR(4, S); break; \
                case 5: SF_SLR(5, S); break; case 6: SF_SLR(6, S); break; case 7: SF_SLR(7, S); break; default: SF_SLR(8, S); break; }

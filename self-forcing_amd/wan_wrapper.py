@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import glob
 import os
+import time
 from typing import Dict, List, Optional
 
 import torch
@@ -97,9 +98,10 @@ class WanDiffusionWrapper(torch.nn.Module):
     # stream's launch queue is full -- and then SPINS inside the HIP runtime for room (measured: the thread's CPU time inside
     # sf_dit_forward equals its wall time, one busy core per rollout thread).  With one process per GPU and two rollout
     # threads per process that is 16 spinning cores on an 8-GPU node for nothing.  Instead the wrapper keeps at most
-    # `max_inflight_forwards` passes enqueued (per wrapper = per stream) and waits for the oldest one on an event created
-    # with blocking sync: the thread sleeps in the kernel instead of spinning.  Two passes in flight keep >= 25 ms of work
-    # queued, so the GPU never waits for the host.  0 disables the pacing.
+    # `max_inflight_forwards` passes enqueued (per wrapper = per stream) and waits for the oldest one by POLLING its event
+    # between 1 ms sleeps (hipEventSynchronize spins too, also on events created with blocking sync: measured 2.5 busy cores
+    # per rank with it, against 1.7 unpaced).  Two passes in flight keep >= 25 ms of work queued, so the GPU never waits
+    # for the host and a millisecond of polling granularity costs nothing.  0 disables the pacing.
     max_inflight_forwards = 2
 
     def _init_throttle(self) -> None:
@@ -110,11 +112,13 @@ class WanDiffusionWrapper(torch.nn.Module):
         n = self.max_inflight_forwards
         if n <= 0 or torch.compiler.is_compiling():
             return
-        ev = torch.cuda.Event(blocking=True)
+        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
         self._inflight.append(ev)
         while len(self._inflight) > n:
-            self._inflight.popleft().synchronize()
+            oldest = self._inflight.popleft()
+            while not oldest.query():
+                time.sleep(0.001)
 
     def share(self) -> "WanDiffusionWrapper":
         """A second wrapper over the SAME device weights (own pointer tables / scratch), for a second
