@@ -108,6 +108,24 @@ class BoardSampler:
                         "see 1.5-1.7 GHz of effective clock under this load (DESIGN.md section 4)"}
 
 
+def thread_cpu_seconds():
+    """{tid: (comm, user + system CPU seconds)} of every thread of this process (/proc/self/task): who uses the host."""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    st = f.read()
+                comm = st[st.index("(") + 1:st.rindex(")")]
+                rest = st[st.rindex(")") + 2:].split()
+                out[int(tid)] = (comm, (int(rest[11]) + int(rest[12])) / tick)
+            except (OSError, ValueError, IndexError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def usable_cores():
     """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -363,7 +381,15 @@ def cpu_baseline_leg(shape, sd, frames_sample, nfpb, n_steps, total_frames):
         lat = wo.rollout(W, cfg, targs, Tn, pe, eps)
         dt_T = time.time() - t0
     assert torch.isfinite(lat.float()).all()
-    return {"value": DECODED_PER_LATENT(2) / dt_T, "unit": "decoded frames/s", "cores": cores, "kind": "port",
+    s1_ref = None
+    try:   # the kept one-off: the S1 clip itself on a GPU box's host cores (tools/cpu_s1_clip.py; too long for this leg)
+        with open(os.path.join(ROOT, "profiles", "r03_cpu_s1_clip.json")) as f:
+            r = json.load(f)
+        s1_ref = {"value": r["frames_per_s"], "unit": "decoded frames/s", "seconds_per_clip": r["seconds"], "cores": r["threads"],
+                  "cpu_model": r["cpu_model"], "measured": r["measured"], "source": "profiles/r03_cpu_s1_clip.json (committed; not measured in this run)"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"value": DECODED_PER_LATENT(2) / dt_T, "unit": "decoded frames/s", "cores": cores, "kind": "port", "s1_measured_ref": s1_ref,
             "sample": f"MEASURED: one whole config-T rollout of the CPU oracle (bf16, the reference's CPU path): 2 latent = 5 decoded "
                       f"frames, 2 chunks x (4 + 1) forwards of {fs} tokens, {dt_T:.1f} s",
             "rollout_seconds": dt_T,
@@ -478,9 +504,11 @@ def main():
     host_enqueue_stats(reset=True)
     if board is not None and world == 1:
         board.__enter__()
-    cpu0 = time.process_time()
+    cpu0, thr0 = time.process_time(), thread_cpu_seconds()
     elapsed, local_elapsed, lats = grp.timed(lambda: pool.run(list(range(a.warmup, total)), one_step))
     proc_cpu = time.process_time() - cpu0                       # CPU seconds of ALL threads of this rank (incl. the sampler's)
+    thr1 = thread_cpu_seconds()
+    by_thread = sorted(((thr1[t][1] - thr0.get(t, (None, 0.0))[1], thr1[t][0]) for t in thr1), reverse=True)
     if board is not None and world == 1:
         board.__exit__()
     fw_calls, fw_secs, fw_cpu, fw_threads = host_enqueue_stats()
@@ -537,6 +565,7 @@ def main():
         "host_enqueue_wall_ms_per_forward": 1e3 * fw_secs / max(1, fw_calls),
         "host_busy_cores": proc_cpu / max(local_elapsed, 1e-9),
         "host_cores_available": usable_cores(),
+        "host_busy_cores_by_thread": [{"thread": name, "busy_cores": round(sec / max(local_elapsed, 1e-9), 3)} for sec, name in by_thread[:6] if sec > 0],
         "host_note": f"{fw_calls} forwards enqueued by {fw_threads} Python thread(s) in the timed region on rank 0. "
                      "host_enqueue_ms_per_forward = CPU time of the calling thread inside sf_dit_forward (the C call that enqueues a "
                      "pass's ~430 launches); _wall_ = wall time inside it, which includes waiting for room in the stream's launch "
