@@ -703,7 +703,8 @@ __global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
     for (int i = 0; i < 4; ++i) {   // this wave's LDS-DMA pieces 4 wave + i: 4 rows x 256 B each, swizzle on the source
       const int row = (wave * 4 + i) * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-      prm[16 + i] = (unsigned)(((long)row * p.kv_stride + chunk * 8) * 2);
+      // (minus the i KiB the instruction's immediate offset adds back: piece i's LDS address is M0 + i KiB, set once per group)
+      prm[16 + i] = (unsigned)(((long)row * p.kv_stride + chunk * 8) * 2 - i * 1024);
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {

@@ -46,6 +46,9 @@ if "--abl" in sys.argv:
 
 ALIGN = int(sys.argv[sys.argv.index("--align") + 1]) if "--align" in sys.argv else 6    # log2 bytes; 0 = none
 PAD = int(sys.argv[sys.argv.index("--pad") + 1]) if "--pad" in sys.argv else 0          # extra 4-byte s_nops behind it
+# where a tile's eight LDS-DMA requests are issued: K pieces placed in phases A / B, V pieces in C / D ("n_in_A,n_in_C":
+# how many of the four go to the FIRST phase of each pair; 0,0 = all four K requests in B and all four V requests in D)
+DMA_SPLIT = [int(x) for x in (sys.argv[sys.argv.index("--dma-split") + 1] if "--dma-split" in sys.argv else "0,0").split(",")]
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "self-forcing_amd", "csrc",
                    "attention_r64_asm.inc")
@@ -347,8 +350,12 @@ def dma_items(srd, soff_sreg, slot_sreg, prologue=False):
         return []
     it = []
     for i in range(4):
-        txt = [f"s_add_u32 s{STMP2}, s{slot_sreg}, {LDS_WAVE}", f"s_add_u32 m0, s{STMP2}, {i * 1024}", "s_nop 1",
-               f"buffer_load_dwordx4 {vr(DMAOFF[i])}, {srd}, s{soff_sreg} offen lds"]
+        # ONE M0 per group of four pieces: piece i's LDS address is M0 + inst_offset (i KiB) + 16 lane, and the same
+        # inst_offset is taken back out of the piece's global byte offset (DMAOFF[i], prepared by the C++ prologue), so the
+        # global address and its range check are unchanged.  (M0 per piece was two SALU + a wait state each: 8 pieces a tile.)
+        txt = [f"buffer_load_dwordx4 {vr(DMAOFF[i])}, {srd}, s{soff_sreg} offen" + (f" offset:{i * 1024}" if i else "") + " lds"]
+        if i == 0:
+            txt = [f"s_add_u32 m0, s{slot_sreg}, {LDS_WAVE}", "s_nop 1"] + txt
         it.append(("raw", "\n\t".join(txt)))
     return it
 
@@ -359,10 +366,14 @@ def dma(srd, soff_sreg, slot_sreg, prologue=False):
 
 
 def set_kcur(slot_sreg):
+    if "noaddr" in ABL:      # timing-only: what the per-tile ring addressing costs (upper bound of unrolling the rings)
+        return []
     return [("valu", f"v_add_u32 {vr(KCUR[s])}, s{slot_sreg}, {vr(KADDR[s])}") for s in range(8)]
 
 
 def set_vcur(slot_sreg):
+    if "noaddr" in ABL:
+        return []
     return ([("valu", f"v_add_u32 {vr(VCURLO[d])}, s{slot_sreg}, {vr(VLO[d])}") for d in range(4)]
             + [("valu", f"v_add_u32 {vr(VCURHI[d])}, s{slot_sreg}, {vr(VHI[d])}") for d in range(4)])
 
@@ -398,16 +409,19 @@ def body(kind):
         e(f"s_sub_i32 s{SLIM}, {LK}, s{STMP}")
     # A: QK(u1) -> S1 || exp2 / convert of u0 (S0 -> P) || V^T fragments of u0
     rescale_check(0)
-    phase(qk_mfmas(1), mix(exp_items(0), v_reads(0)))
+    ka, vc = DMA_SPLIT
+    phase(qk_mfmas(1), mix(mix(exp_items(0), v_reads(0)), dma_k[:ka]))
     # B: PV(u0) || row sums of u0, row maxima of u1 || K fragments of unit 0 of tile t+1 || request K(t+3)
     pad = [("valu", "s_nop 7"), ("valu", "s_nop 7")] if last else []
-    phase(pv_mfmas(), mix(sum_items(0) + ([] if last else set_kcur(KS_N1)) + pad + mix(max_items(1, last, 1), [] if last else k_reads(0)), dma_k))
+    phase(pv_mfmas(), mix(sum_items(0) + ([] if last else set_kcur(KS_N1)) + pad + mix(max_items(1, last, 1), [] if last else k_reads(0)), dma_k[ka:]))
     # C: QK(2t+2) -> S0 || exp2 / convert of u1 (S1 -> P) || V^T fragments of u1
     rescale_check(1)
-    phase([] if last else qk_mfmas(0), v_reads(1) + exp_items(1) if last else mix(exp_items(1), v_reads(1)))
+    phase([] if last else qk_mfmas(0), v_reads(1) + exp_items(1) if last else mix(mix(exp_items(1), v_reads(1)), dma_v[:vc]))
     # D: PV(u1) || row sums of u1, row maxima of unit 2t+2 || K fragments of unit 1 of tile t+1 || request V(t+2)
-    phase(pv_mfmas(), mix(sum_items(1) + ([] if last else mix(max_items(0, kind == "penult", 0), k_reads(1))), dma_v))
-    if not last:
+    phase(pv_mfmas(), mix(sum_items(1) + ([] if last else mix(max_items(0, kind == "penult", 0), k_reads(1))), dma_v[vc:]))
+    if not last and "noaddr" in ABL:
+        e(f"s_add_u32 s{ST}, s{ST}, 1")
+    elif not last:
         # rotate the rings: K (cur, n1, n2, dma) <- (n1, n2, dma, cur); V (cur, n1, dma) <- (n1, dma, cur)
         e(f"s_mov_b32 s{STMP}, s{KS_CUR}")
         e(f"s_mov_b32 s{KS_CUR}, s{KS_N1}")
