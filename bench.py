@@ -57,37 +57,79 @@ def log(msg):
 
 
 class BoardSampler:
-    """Socket power and reported shader clock of this rank's GPU during the timed region, sampled from `rocm-smi` in a
-    background thread (one subprocess call per ~0.5 s: host-side only).  Reported beside the rates because the MFMA
-    kernels of this path run at the board's power limit; None when rocm-smi is unavailable."""
+    """Socket power and reported shader clock of this rank's GPU during the timed region, sampled in a background thread.
+    Read from the amdgpu sysfs files of the device (hwmon power1_average / power1_input, pp_dpm_sclk, power1_cap) -- plain
+    file reads; `rocm-smi` is only the fallback: it is a Python program, and starting it every 0.5 s from a process with
+    torch and a 300 GB GPU address space mapped cost 0.85 of a host core (measured, round 3).  Reported beside the rates
+    because the MFMA kernels of this path run at the board's power limit; None when neither source
+    is available."""
 
     def __init__(self, device_index, period=0.5):
+        import glob
         import re
         import subprocess
         import threading
-        self._re_clk = re.compile(r"sclk clock level[^\n]*\((\d+)Mhz\)")
-        self._re_pw = re.compile(r"(?:Average|Current Socket) Graphics Package Power \(W\): ([0-9.]+)")
-        self._sp, self._stop, self.samples = subprocess, False, []
-        self._cmd = ["rocm-smi", "--showclocks", "--showpower", "-d", str(device_index)]
-        self._period = period
-        self.limit_w = None
-        try:
-            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)",
-                            subprocess.run(["rocm-smi", "--showmaxpower", "-d", str(device_index)], capture_output=True, text=True, timeout=5).stdout)
-            self.limit_w = float(cap.group(1)) if cap else None
+        self._stop, self.samples, self._period, self.limit_w = False, [], period, None
+        self._sp, self._re = subprocess, re
+        self._power_file = self._sclk_file = None
+        self.source = None
+        try:   # the PCI address of HIP device `device_index` -> its sysfs directory
+            pr = torch.cuda.get_device_properties(device_index)
+            dom = getattr(pr, "pci_domain_id", 0)
+            pci = f"{dom:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            base = f"/sys/bus/pci/devices/{pci}"
+            for name in ("power1_average", "power1_input"):
+                hits = glob.glob(f"{base}/hwmon/hwmon*/{name}")
+                if hits:
+                    self._power_file = hits[0]
+                    break
+            if os.path.exists(f"{base}/pp_dpm_sclk"):
+                self._sclk_file = f"{base}/pp_dpm_sclk"
+            cap = glob.glob(f"{base}/hwmon/hwmon*/power1_cap")
+            if cap:
+                self.limit_w = int(open(cap[0]).read()) / 1e6
+            if self._power_file and self._sclk_file:
+                self._read_sysfs()            # (raises if unreadable)
+                self.source = "amdgpu sysfs (hwmon power, pp_dpm_sclk)"
         except Exception:   # noqa: BLE001
-            pass
+            self.source = None
+        if self.source is None:
+            self._re_clk = re.compile(r"sclk clock level[^\n]*\((\d+)Mhz\)")
+            self._re_pw = re.compile(r"(?:Average|Current Socket) Graphics Package Power \(W\): ([0-9.]+)")
+            self._cmd = ["rocm-smi", "--showclocks", "--showpower", "-d", str(device_index)]
+            self._period = max(period, 2.0)
+            try:
+                cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)",
+                                subprocess.run(["rocm-smi", "--showmaxpower", "-d", str(device_index)], capture_output=True, text=True, timeout=5).stdout)
+                self.limit_w = float(cap.group(1)) if cap else None
+                self.source = "rocm-smi (one process per sample)"
+            except Exception:   # noqa: BLE001
+                pass
         self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read_sysfs(self):
+        watts = int(open(self._power_file).read()) / 1e6
+        mhz = None
+        for ln in open(self._sclk_file):
+            if "*" in ln:
+                m = self._re.search(r"(\d+)Mhz", ln)
+                mhz = int(m.group(1)) if m else None
+        return mhz, watts
 
     def _run(self):
         while not self._stop:
             try:
-                out = self._sp.run(self._cmd, capture_output=True, text=True, timeout=5).stdout
-            except Exception:   # noqa: BLE001  (no rocm-smi on this box: report nothing)
+                if self._power_file and self._sclk_file and self.source and self.source.startswith("amdgpu"):
+                    c, w = self._read_sysfs()
+                    if c is not None:
+                        self.samples.append((c, w))
+                else:
+                    out = self._sp.run(self._cmd, capture_output=True, text=True, timeout=5).stdout
+                    c, w = self._re_clk.search(out), self._re_pw.search(out)
+                    if c and w:
+                        self.samples.append((int(c.group(1)), float(w.group(1))))
+            except Exception:   # noqa: BLE001  (no source on this box: report nothing)
                 return
-            c, w = self._re_clk.search(out), self._re_pw.search(out)
-            if c and w:
-                self.samples.append((int(c.group(1)), float(w.group(1))))
             time.sleep(self._period)
 
     def __enter__(self):
@@ -103,9 +145,9 @@ class BoardSampler:
             return None
         clk, pw = sorted(c for c, _ in self.samples), sorted(w for _, w in self.samples)
         return {"samples": len(self.samples), "socket_power_w_median": pw[len(pw) // 2], "socket_power_w_max": pw[-1],
-                "sclk_reported_mhz_median": clk[len(clk) // 2], "socket_power_limit_w": self.limit_w,
-                "note": "rocm-smi during the timed region (every ~0.5 s; the limit from --showmaxpower); in-kernel cycle counters "
-                        "see 1.5-1.7 GHz of effective clock under this load (DESIGN.md section 4)"}
+                "sclk_reported_mhz_median": clk[len(clk) // 2], "socket_power_limit_w": self.limit_w, "source": self.source,
+                "note": "sampled every ~0.5 s; in-kernel cycle counters see 1.5-1.7 GHz of effective clock under this load "
+                        "(DESIGN.md section 4)"}
 
 
 def thread_cpu_seconds():
@@ -437,13 +479,22 @@ def main():
         # torch.distributed.run; this process has made no GPU call (nothing above touches the device) and only waits.
         log(f"--gpus {a.gpus} without a torchrun environment: starting {a.gpus} rank processes")
         raise SystemExit(sfd.self_launch(os.path.abspath(__file__), sys.argv[1:], a.gpus, timeout=a.launch_timeout))
+    # stdout carries ONE line, rank 0's JSON: libraries that write to file descriptor 1 on their own (RCCL prints a
+    # five-line version banner there at init) are pointed at stderr for the rest of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     rank, local_rank, world = sfd.env_rank_world()
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without torchrun)")
     if a.dist_selftest:
         rep = sfd.selftest(steps=a.steps, warmup=a.warmup)
         if rank == 0:
-            print(json.dumps(rep), flush=True)
+            emit(rep)
         return
     LAT_H, LAT_W = a.latent_height, a.latent_width
     if a.rollout_only:
@@ -692,7 +743,7 @@ def main():
                                       f"{cfg_frames} latent frames of a clip, so the cache is at most {cfg_frames * fs} tokens long"}
     if heavy and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(shape, sd, nfpb, nfpb, len(step_list), a.frames)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 if __name__ == "__main__":

@@ -59,14 +59,17 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, port: Optional[int
 
 
 class RankGroup:
-    """The protocol above over torch.distributed; with world == 1 every method is the identity (no process group)."""
+    """The protocol above over torch.distributed; outside torch.distributed.run (world == 1) every method is the identity
+    (no process group)."""
 
     def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, timeout_s: float = 1800.0):
         self.rank, self.local_rank, self.world = env_rank_world()
         self.device = device if device is not None else torch.device("cpu")
         self.backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
         self.dist = None
-        if self.world > 1:
+        # a process group whenever torch.distributed.run started us -- also with ONE rank, so that the RCCL code path
+        # (init with device_id, all_reduce MIN / MAX, barrier, all_gather, destroy) can be exercised on a one-GPU box
+        if self.world > 1 or launched_by_torchrun():
             import torch.distributed as dist
             kw = {"device_id": self.device} if self.backend == "nccl" else {}
             dist.init_process_group(backend=self.backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)

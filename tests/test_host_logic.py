@@ -266,7 +266,7 @@ def test_rank_group_single_process_is_the_identity():
     from self_forcing_amd.distributed import RankGroup, launched_by_torchrun
     assert not launched_by_torchrun() or "RANK" in os.environ
     grp = RankGroup(backend="gloo")
-    if grp.world == 1:
+    if grp.world == 1 and not launched_by_torchrun():
         assert grp.dist is None and grp.check_replicas(3.0) == 3.0
         el, loc, res = grp.timed(lambda: 5)
         assert res == 5 and el >= loc >= 0 and grp.gather([1, 2]) == [[1.0, 2.0]]
