@@ -152,7 +152,9 @@ class BoardSampler:
 
 def thread_cpu_seconds():
     """{tid: (comm, user + system CPU seconds)} of every thread of this process (/proc/self/task): who uses the host."""
+    import threading
     out, tick = {}, os.sysconf("SC_CLK_TCK")
+    py_threads = {t.native_id for t in threading.enumerate()}
     try:
         for tid in os.listdir("/proc/self/task"):
             try:
@@ -160,6 +162,10 @@ def thread_cpu_seconds():
                     st = f.read()
                 comm = st[st.index("(") + 1:st.rindex(")")]
                 rest = st[st.rindex(")") + 2:].split()
+                if int(tid) == os.getpid():
+                    comm += " (main thread)"
+                elif int(tid) not in py_threads:
+                    comm += " (not a Python thread: HIP / HSA runtime helper)"
                 out[int(tid)] = (comm, (int(rest[11]) + int(rest[12])) / tick)
             except (OSError, ValueError, IndexError):
                 pass
