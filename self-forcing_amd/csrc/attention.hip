@@ -623,7 +623,31 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (qrow < p.Lq) {
+  // The lane pair (l, l + 32) holds the two 8-byte halves of 16 contiguous output bytes (d = 8 g + 4 hh + 0..3).  With
+  // 16-byte aligned output rows one v_permlane32_swap per dword regroups them: lane l stores the whole even 16-byte group,
+  // lane l + 32 the odd one -- 8 x dwordx4 per lane instead of 16 x dwordx2 (the store tail of an attention epilogue is
+  // issue-bound: cdna_hip_programming.md T21).  Validity is per query row, i.e. the same for both lanes of a pair.
+  const bool wide = (((uintptr_t)obase | (uintptr_t)(p.o_stride * 2)) & 15) == 0;
+  if (wide) {
+    bf16_t* op = obase + (long)min(qrow, p.Lq - 1) * p.o_stride + 8 * hh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        unsigned wd[2][2];                      // [group 2 pr + g][dword]
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const bf16x2 pk = {(bf16_t)(o_acc[db][4 * (2 * pr + g) + 2 * d] * inv), (bf16_t)(o_acc[db][4 * (2 * pr + g) + 2 * d + 1] * inv)};
+            wd[g][d] = __builtin_bit_cast(unsigned, pk);
+          }
+        const auto s0 = __builtin_amdgcn_permlane32_swap(wd[0][0], wd[1][0], false, false);   // {[A0.lo, B0.lo], [A0.hi, B0.hi]}
+        const auto s1 = __builtin_amdgcn_permlane32_swap(wd[0][1], wd[1][1], false, false);
+        const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+        if (qrow < p.Lq) *reinterpret_cast<u32x4*>(op + db * 32 + pr * 16) = v;
+      }
+  } else if (qrow < p.Lq) {
     bf16_t* op = obase + (long)qrow * p.o_stride + 4 * hh;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -646,6 +670,7 @@ __global__ __launch_bounds__(ATT8_THREADS, 2) void attention_w8_kernel(AttP p) {
 constexpr int QT64 = 256;                      // 4 waves x 64 rows
 constexpr int ATT64_LDS = 7 * TILE_B;          // K ring of 4 + V ring of 3 = 112 KiB
 
+template <int KIND>   // 0: keys = the KV cache (self-attention), 1: short key sequences (cross-attention): distinct symbols for profiles
 __global__ __launch_bounds__(256) void attention_r64_kernel(AttP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -777,17 +802,23 @@ extern "C" int sf_attention_ex(const void* q, const void* k, const void* v, void
   const long nwg8 = (long)((Lq + QT8 - 1) / QT8) * H * B;
   // (the 64-row kernel stores 16 bytes per lane: it needs 16-byte aligned output rows)
   const bool out16 = ((uintptr_t)out % 16 == 0) && o_stride % 8 == 0 && o_bstride % 8 == 0;
+  // (round 3: with its shorter prologue / epilogue the 64-row kernel is ahead of the 8-wave one from 512 keys on --
+  // cross-attention, Lk = 512: 21.2 vs 22.1 us at one prompt, 41.7 vs 43.1 at two; Lk = 256: 15.8 vs 14.8)
   if (structure == SF_ATTN_AUTO)
-    structure = (nwg64 >= 192 && Lk > 1024 && out16) ? SF_ATTN_R64 : nwg8 >= 192 ? SF_ATTN_W8 : SF_ATTN_W4;
+    structure = (nwg64 >= 192 && Lk >= 512 && out16) ? SF_ATTN_R64 : nwg8 >= 192 ? SF_ATTN_W8 : SF_ATTN_W4;
   if (structure == SF_ATTN_R64) {
     SF_CHECK(out16, "sf_attention: the r64 structure needs 16-byte aligned output rows (out %% 16, o_stride %% 8, o_bstride %% 8)");
     p.q_tiles = (Lq + QT64 - 1) / QT64;
-    static bool attr = false;   // one-time registration of the kernel's LDS size (idempotent; no other state is kept)
+    static bool attr = false;   // one-time registration of the kernels' LDS size (idempotent; no other state is kept)
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_r64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT64_LDS);
       attr = true;
     }
-    hipLaunchKernelGGL(attention_r64_kernel, dim3((unsigned)nwg64), dim3(256), ATT64_LDS, (hipStream_t)stream, p);
+    if (Lk > 1024)
+      hipLaunchKernelGGL(attention_r64_kernel<0>, dim3((unsigned)nwg64), dim3(256), ATT64_LDS, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL(attention_r64_kernel<1>, dim3((unsigned)nwg64), dim3(256), ATT64_LDS, (hipStream_t)stream, p);
     SF_HIP_LAUNCH_CHECK("sf_attention");
     return 0;
   }
