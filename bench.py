@@ -473,6 +473,8 @@ def parse_args(argv=None):
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the multi-rank protocol on CPU over gloo with no GPU work and print its report (tests)")
     ap.add_argument("--launch-timeout", type=float, default=None, help="seconds the self-launched rank processes may take")
+    ap.add_argument("--max-inflight", type=int, default=None,
+                    help="host pacing: passes a wrapper keeps enqueued before its thread sleeps (default: the wrapper's 2; 0 = unpaced)")
     return ap.parse_args(argv)
 
 
@@ -521,6 +523,8 @@ def main():
                            num_frame_per_block=nfpb, context_noise=0)
     gen = sfa.WanDiffusionWrapper(shape=shape, state_dict=sd, timestep_shift=shift, is_causal=True, device=dev,
                                   local_attn_size=a.local_attn_size, sink_size=a.sink_size)
+    if a.max_inflight is not None:
+        sfa.WanDiffusionWrapper.max_inflight_forwards = a.max_inflight
     window = a.local_attn_size if a.local_attn_size > 0 else 0
     enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=dev)
     pool = sfa.RolloutPool(args, dev, gen, lambda: enc, sfa.IdentityVAE, streams=a.streams)

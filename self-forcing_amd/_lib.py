@@ -9,6 +9,14 @@ import os
 import subprocess
 from typing import Optional
 
+# A default for the HIP runtime, set before anything has initialised it (it reads the variable once, at start-up; a value
+# the user has set wins): with the runtime's default signal pool a steady stream of ~430 launches per forward keeps one of
+# its helper threads spinning for signals to come free -- 0.83 of a host core per process, measured on MI355X / ROCm 7.0
+# (bench.py: host_busy_cores_by_thread); with 256 or more signals in the pool that thread idles (0.004).  Together with
+# the wrapper's pacing (wan_wrapper.py) a rank needs 0.17 of a core instead of 1.0-1.7; throughput is unchanged.
+# (The C library itself reads no environment variables; this is the Python host layer configuring the runtime under it.)
+os.environ.setdefault("ROC_SIGNAL_POOL_SIZE", "1024")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(CSRC, "libsf_hip.so")   # SF_HIP_LIB: alternate builds (kernel ablation timing)

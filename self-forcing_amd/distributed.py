@@ -54,6 +54,7 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, port: Optional[int
            "--master-port", str(port), script, *argv]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("ROC_SIGNAL_POOL_SIZE", "1024")         # (see _lib.py: keeps a runtime helper thread from spinning)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, nproc))))
     return subprocess.run(cmd, env=env, timeout=timeout).returncode
 

@@ -415,6 +415,32 @@ def test_add_condition_identity_projection_on_dim_5120_models():
         small(x.to(DEV), {"prompt_embeds": pe2, "add_condition": cond.to(DEV)}, t.to(DEV), p2.kv_cache1, p2.crossattn_cache, 0)
 
 
+def test_host_pacing_bounds_the_queue_and_changes_nothing(sd_reduced):
+    """`WanDiffusionWrapper.max_inflight_forwards` (host-side pacing: the calling thread polls the oldest pass's event
+    between sleeps instead of spinning for launch-queue room): never more than that many passes' events outstanding, and
+    the latents are bit-identical with the pacing off."""
+    g = torch.Generator().manual_seed(61)
+    noise = torch.randn(1, 4, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    eps = [torch.randn(2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(6)]
+    outs = []
+    for limit in (2, 0, 1):
+        pipe = make_pipe(sd_reduced, 2, False, 5.0, pe=pe)
+        pipe.generator.max_inflight_forwards = limit
+        q = list(eps)
+        pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+        seen = []
+        orig = pipe.generator._pace
+
+        def pace(device, _orig=orig, _gen=pipe.generator):
+            _orig(device)
+            seen.append(len(_gen._inflight))
+        pipe.generator._pace = pace
+        outs.append(pipe.inference(noise, ["p"], return_latents=True)[1].clone())
+        assert len(seen) == 10 and max(seen) <= max(limit, 0)      # 2 chunks x (4 + 1) passes
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def _conv_corunner(g):
     """The co-runner that triggered the packed-fp32 fault: a 3x3x3 convolution whose gathered
     k-loop is 54 slices long; returns a function that enqueues `n` of them on the current stream."""

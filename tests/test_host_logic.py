@@ -484,3 +484,23 @@ def test_default_components_need_the_reference_checkpoints(tmp_path, monkeypatch
     with pytest.raises(FileNotFoundError, match="VAE checkpoint"):
         sfa.WanVAEWrapper(device="cpu")
     assert sfa.text_encoder.HuggingfaceTokenizer.clean("  a &amp;amp; b \n\t c ") == "a & b c"
+
+
+def test_bench_reads_counter_traffic_only_at_the_profiled_shape():
+    """bench.py's roofline.traffic comes from the committed rocprofv3 --pmc pass ONLY when that pass was taken at the
+    shape and batch being reported; anything else is null (round 2 reported the 1.3B figure beside a 14B run)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lks = [4680 * i for i in range(1, 8)]
+    t1, src1 = bench.committed_traffic(sfa.WAN_1_3B, 4680, lks, 1, 0)
+    t2, src2 = bench.committed_traffic(sfa.WAN_1_3B, 4680, lks, 2, 0)
+    assert t1 and t2 and 1.9 < t2 / t1 < 2.1 and "r03_pmc_traffic.json" in src1 and "batch2" in src2
+    assert bench.committed_traffic(sfa.WAN_14B, 10800, [10800 * i for i in range(1, 8)], 1, 0)[0] is None      # another model
+    assert bench.committed_traffic(sfa.WAN_1_3B, 4680, lks[:5], 1, 0)[0] is None                                  # other cache lengths
+    assert bench.committed_traffic(sfa.WAN_1_3B, 4680, lks, 3, 0)[0] is None                                      # unprofiled batch
+    assert bench.committed_traffic(sfa.WAN_1_3B, 4680, lks, 1, 21)[0] is None                                     # rolling window
+    # algorithmic FLOPs of the S1 rollout (SURVEY 8d: 990 TFLOP) and what the context passes skip
+    full = bench.rollout_flops(sfa.WAN_1_3B, 21, 3, 4, 1560)
+    assert abs(full / 1e12 - 990.3) < 1.0 and bench.rollout_flops(sfa.WAN_1_3B, 21, 3, 4, 1560, executed=True) < full
