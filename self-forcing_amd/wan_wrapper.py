@@ -110,7 +110,7 @@ class WanDiffusionWrapper(torch.nn.Module):
 
     def _pace(self, device) -> None:
         n = self.max_inflight_forwards
-        if n <= 0 or torch.compiler.is_compiling():
+        if n <= 0 or torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing():
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
