@@ -48,3 +48,16 @@ def test_no_hazardous_packed_fp32_in_shipped_kernels():
     assert not bad, "\n".join(bad)
     # the allow-listed kernel really is the only holder, and only of the plain form
     assert all(any(k in kernel for k in ALLOWED) for kernel in census), census.keys()
+
+
+def test_compressed_bundle_headers_are_cut_by_their_total_size():
+    """`.hip_fatbin` sections of PyTorch's own libraries hold zstd-compressed `CCOB` bundles back to back (libtorch_hip.so:
+    274 of them, no plain one): the census tool cuts them out by the total size in each header (version 2: u32, version 3:
+    u64) and skips a 'CCOB' that does not parse as a header (bytes inside compressed data)."""
+    import struct
+    v2 = b"CCOB" + struct.pack("<HHIIQ", 2, 1, 24 + 10, 100, 0xABCD) + b"x" * 10
+    v3 = b"CCOB" + struct.pack("<HHQQQ", 3, 1, 32 + 7, 55, 0x1234) + b"CCOByyy"          # payload that contains the magic
+    blob = b"\0" * 5 + v2 + b"\0" * 3 + v3 + b"CCOB" + struct.pack("<HH", 9, 7) + b"junk"
+    got = list(co.compressed_bundles(blob))
+    assert got == [v2, v3]
+    assert list(co.compressed_bundles(b"no bundles here")) == []
