@@ -473,6 +473,10 @@ def parse_args(argv=None):
     ap.add_argument("--dist-selftest", action="store_true",
                     help="run the multi-rank protocol on CPU over gloo with no GPU work and print its report (tests)")
     ap.add_argument("--launch-timeout", type=float, default=None, help="seconds the self-launched rank processes may take")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help="collectives of the N > 1 protocol (nccl = RCCL over xGMI)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 (needs --dist-backend gloo: RCCL "
+                         "refuses two ranks on one device); the figures of such a run are not a scaling measurement")
     ap.add_argument("--max-inflight", type=int, default=None,
                     help="host pacing: passes a wrapper keeps enqueued before its thread sleeps (default: the wrapper's 2; 0 = unpaced)")
     return ap.parse_args(argv)
@@ -509,9 +513,11 @@ def main():
         a.no_roofline = a.no_vae = a.no_cpu_baseline = True
         a.cfg_frames = 0
 
-    dev = torch.device(f"cuda:{local_rank}")
+    if a.same_device and a.dist_backend == "nccl" and world > 1:
+        raise SystemExit("--same-device needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    dev = torch.device("cuda:0" if a.same_device else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
-    grp = sfd.RankGroup(backend="nccl", device=dev)             # RCCL over xGMI; no process group at world == 1
+    grp = sfd.RankGroup(backend=a.dist_backend, device=dev)     # RCCL over xGMI by default; no process group outside torchrun
 
     torch.set_num_threads(max(1, min(usable_cores() // max(1, world), 16)))
     log(f"rank {rank}/{world} on {dev}; synthesising weights")
@@ -549,7 +555,7 @@ def main():
     log(f"model resident ({gen.model.param_bytes() / 1e9:.2f} GB); warmup x{a.warmup}, {a.streams} stream(s)")
     # the board sampler starts a rocm-smi process every 0.5 s: inside the timed region only when this is the one rank
     # of the job; with several ranks it watches the warm-up instead (same kernels, no effect on the timed region)
-    board = BoardSampler(local_rank) if rank == 0 else None
+    board = BoardSampler(dev.index or 0) if rank == 0 else None
     tw = time.perf_counter()
     if board is not None and world > 1:
         board.__enter__()
@@ -612,7 +618,8 @@ def main():
                                + f"{B} prompt(s) per rollout call, {a.streams} rollout call(s) in flight per GPU "
                                f"(one HIP stream each, shared weights), prompts sharded rank::N",
                    "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
-                   "parallelism": f"prompt-sharded x{world}", "streams_per_gpu": a.streams, "batch_per_rollout": B},
+                   "parallelism": f"prompt-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo collectives)" if a.same_device and world > 1 else ""),
+                   "streams_per_gpu": a.streams, "batch_per_rollout": B},
         "algorithmic_tflop_per_step": flops / 1e12,
         "executed_tflop_per_step": flops_exec / 1e12,
         "achieved_tflops_per_gpu": flops_exec * a.steps / elapsed / 1e12,
