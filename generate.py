@@ -68,15 +68,11 @@ def main():
     ap.add_argument("--vae_random_init_seed", type=int, default=None, help="seeded random VAE decoder weights instead")
     a = ap.parse_args()
 
-    dist = None
-    if "LOCAL_RANK" in os.environ:   # inference.py:39-45
-        import torch.distributed as dist
-        local_rank = int(os.environ["LOCAL_RANK"])
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        rank, world = dist.get_rank(), dist.get_world_size()
-    else:
-        local_rank, rank, world = 0, 0, 1
+    # inference.py:39-45: one process per GPU under torch.distributed.run, RCCL for the start / end barriers only
+    from self_forcing_amd.distributed import RankGroup, env_rank_world
+    rank, local_rank, world = env_rank_world()
+    torch.cuda.set_device(local_rank)
+    grp = RankGroup(backend="nccl", device=torch.device(f"cuda:{local_rank}"))
     device = torch.device(f"cuda:{local_rank}")
     torch.manual_seed(a.seed + rank)
     torch.set_grad_enabled(False)
@@ -118,8 +114,7 @@ def main():
 
     if rank == 0:
         os.makedirs(a.output_folder, exist_ok=True)
-    if dist is not None:
-        dist.barrier()
+    grp.barrier()
 
     for idx in shard_indices(len(prompts), rank, world):
         noise = torch.randn([a.num_samples, a.num_output_frames, 16, a.latent_height, a.latent_width], device=device,
@@ -134,9 +129,7 @@ def main():
                 torch.save((255.0 * video[s].permute(0, 2, 3, 1)).to(torch.uint8).cpu(), os.path.join(a.output_folder, f"{idx}-{s}.video.pt"))
         if rank == 0:
             print(f"[generate] prompt {idx}: latents {tuple(latents.shape)}" + (f", video {tuple(video.shape)}" if decode else ""), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.finish()
 
 
 if __name__ == "__main__":
