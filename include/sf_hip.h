@@ -244,6 +244,16 @@ typedef struct sf_forward_args {
 size_t sf_dit_workspace_bytes(const sf_model* model, int batch, int frames, int lat_h, int lat_w,
                               int groups);
 int sf_dit_forward(const sf_model* model, const sf_forward_args* args, void* stream);
+/* Two passes of the rollout in ONE call: the context pass of chunk k (`context_pass`, cache_only = 1: it rewrites the
+ * chunk's K / V "clean", causal_inference.py:226-235) and the first denoising pass of chunk k + 1 (`next_pass`,
+ * :190-205), which the reference runs back to back.  Layer l of the second needs only layer l's K / V of the first, so
+ * the two run layer by layer as one batch of 2 x batch samples through every row-wise kernel and GEMM (twice the rows
+ * per GEMM) and one after the other through the cache (eviction, K / V write, attention).  Results are bit-identical to
+ * two sf_dit_forward calls.  Both argument structs must name the same caches, latent geometry, batch and groups, and the
+ * same workspace, sized sf_dit_workspace_bytes(model, 2 * batch, ...); neither may have init_cross set;
+ * `next_pass->kv_index_out` (if any) receives the final indices. */
+int sf_dit_forward_pair(const sf_model* model, const sf_forward_args* context_pass, const sf_forward_args* next_pass,
+                        void* stream);
 
 /* ==========================================================================================
  * Wan VAE decode (latents -> pixels): WanVAEWrapper.decode_to_pixel -> WanVAE_.decode /

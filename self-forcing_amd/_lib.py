@@ -154,6 +154,7 @@ SIGNATURES = {
     "sf_lincomb_bf16": (C.c_int, [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_float), _i, _i64, _vp]),
     "sf_dit_workspace_bytes": (C.c_size_t, [C.POINTER(Model), _i, _i, _i, _i, _i]),
     "sf_dit_forward": (C.c_int, [C.POINTER(Model), C.POINTER(ForwardArgs), _vp]),
+    "sf_dit_forward_pair": (C.c_int, [C.POINTER(Model), C.POINTER(ForwardArgs), C.POINTER(ForwardArgs), _vp]),
     "sf_conv_igemm": (C.c_int, [C.POINTER(ConvArgs), _vp]),
     "sf_conv_pick_nt": (C.c_int, [_i]),
     "sf_rmsnorm_silu_cl": (C.c_int, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

@@ -152,3 +152,16 @@ class CausalWanModel:
             bool(init_cross), bool(cache_only), plan.sink, plan.evict, plan.keep, plan.write_start, plan.attn_start, plan.local_end,
             start_frame, kv_index, plan.global_end)
         return (None, None) if cache_only else (flow, x0)
+
+    def forward_pair(self, ctx_noisy: Tensor, ctx_timestep: Tensor, noisy: Tensor, timestep: Tensor, k_cache: List[Tensor],
+                     v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor], ctx_plan: CachePlan, plan: CachePlan,
+                     ctx_start_frame: int, start_frame: int, evict_scratch: Optional[Tensor] = None, kv_index: Optional[Tensor] = None):
+        """The context pass of chunk k (cache only) + the first denoising pass of chunk k + 1 as ONE call
+        (torch.ops.sf_hip.dit_forward_pair -> sf_dit_forward_pair): bit-identical to two `forward` calls, but every
+        row-wise kernel and GEMM sees both passes' rows at once.  Returns (flow, x0) of the denoising pass."""
+        B, F, Cin, H, W = noisy.shape
+        ws = self.workspace(2 * B, F, H, W, timestep.shape[1])
+        as_list = lambda pl, sf: [pl.sink, pl.evict, pl.keep, pl.write_start, pl.attn_start, pl.local_end, sf]  # noqa: E731
+        return torch.ops.sf_hip.dit_forward_pair(self._handle, ctx_noisy, ctx_timestep, noisy, timestep, k_cache, v_cache, ck_cache, cv_cache,
+                                                 ws, evict_scratch, as_list(ctx_plan, ctx_start_frame), as_list(plan, start_frame), kv_index,
+                                                 plan.global_end)

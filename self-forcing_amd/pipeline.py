@@ -69,6 +69,9 @@ class CausalInferencePipeline(torch.nn.Module):
             self._cache_only_kw = {}
         self.last_profile = None
         self._cache_key = None
+        # run a chunk's context pass together with the next chunk's first denoising pass (one call, same results; see
+        # _denoise_chunks); False = one generator call per pass, as the reference
+        self.pair_context_with_next = True
 
     # ------------------------------------------------------------------------------------------
     def _randn_like(self, t: torch.Tensor) -> torch.Tensor:
@@ -200,6 +203,13 @@ class CausalInferencePipeline(torch.nn.Module):
             tables[f] = (list(per_step.unbind(0)), [t.flatten() for t in per_step.unbind(0)],
                          torch.ones_like(per_step[0]) * ctx_noise)
         n_steps = steps.shape[0]
+        # A chunk's context pass and the next chunk's first denoising pass run back to back in the reference (:226-235, then
+        # :190-205) and layer l of the second needs only layer l's K / V of the first: a generator that offers `forward_pair`
+        # (ours) runs them as ONE call -- bit-identical latents, twice the rows per GEMM (sf_dit_forward_pair).  The re-noise
+        # draws keep their order: nothing is drawn between a chunk's last step and the next chunk's first.
+        pair_ok = bool(self.pair_context_with_next and self._cache_only_kw and hasattr(gen, "forward_pair")
+                       and gen.can_pair(conditional_dict))
+        first_pred = None          # x0 of this chunk's first step when the previous chunk's pair has already computed it
         for chunk_idx, current_num_frames in enumerate(all_num_frames):
             if on_chunk_start is not None:
                 on_chunk_start()
@@ -208,19 +218,30 @@ class CausalInferencePipeline(torch.nn.Module):
             start_tok = current_start_frame * self.frame_seq_length
             step_ts, step_ts_flat, context_timestep = tables[current_num_frames]
             for index in range(n_steps):
-                _, denoised_pred = gen(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
-                                       timestep=step_ts[index], kv_cache=self.kv_cache1,
-                                       crossattn_cache=self.crossattn_cache, current_start=start_tok)
+                if index == 0 and first_pred is not None:
+                    denoised_pred, first_pred = first_pred, None
+                else:
+                    _, denoised_pred = gen(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
+                                           timestep=step_ts[index], kv_cache=self.kv_cache1,
+                                           crossattn_cache=self.crossattn_cache, current_start=start_tok)
                 if index < n_steps - 1:
                     flat = denoised_pred.flatten(0, 1)
                     noisy_input = self.scheduler.add_noise(flat, self._randn_like(flat), step_ts_flat[index + 1]
                                                            ).unflatten(0, denoised_pred.shape[:2])
             yield chunk_idx, current_start_frame, denoised_pred
             # rerun at the context timestep so the cache holds clean K/V (causal_inference.py:226-235)
-            if not (skip_last_context and chunk_idx == len(all_num_frames) - 1):
-                gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
-                    kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok,
-                    **self._cache_only_kw)
+            is_last = chunk_idx == len(all_num_frames) - 1
+            if not (skip_last_context and is_last):
+                if pair_ok and not is_last and all_num_frames[chunk_idx + 1] == current_num_frames:
+                    nxt = current_start_frame + current_num_frames
+                    first_pred = gen.forward_pair(denoised_pred, context_timestep,
+                                                  noise[:, nxt - num_input_frames:nxt + current_num_frames - num_input_frames], step_ts[0],
+                                                  conditional_dict, self.kv_cache1, self.crossattn_cache, start_tok,
+                                                  nxt * self.frame_seq_length)[1]
+                else:
+                    gen(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict, timestep=context_timestep,
+                        kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache, current_start=start_tok,
+                        **self._cache_only_kw)
             if on_chunk_end is not None:
                 on_chunk_end()
             current_start_frame += current_num_frames

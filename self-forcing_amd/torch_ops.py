@@ -15,6 +15,8 @@ tracing, and is opaque-but-legal to `torch.compile` -- which the reference's sec
     sf_hip::add_noise(x0, eps, timestep, sigmas, timesteps) -> out
     sf_hip::dit_forward(model, noisy, timestep, prompt_embeds?, add_condition?, k_cache![], v_cache![], ck_cache![],
                         cv_cache![], workspace!, evict_scratch!?, ..., kv_index!?, global_end) -> (flow, x0)
+    sf_hip::dit_forward_pair(model, ctx_noisy, ctx_timestep, noisy, timestep, caches![]..., workspace!, evict_scratch!?, ctx_plan[7],
+                             plan[7], kv_index!?, global_end) -> (flow, x0)        (context pass of chunk k + first pass of chunk k + 1)
     sf_hip::vae_decode_frames(model, state!, scratch!, z, out!, h, w, window_frames, frame_index, window, history_at) -> ()
     sf_hip::t5_encode(model, ids, mask, buckets, workspace!) -> out
 
@@ -243,18 +245,11 @@ def _pointer_tables(handle: int, k: Sequence[Tensor], v: Sequence[Tensor], ck: S
     return tabs
 
 
-@custom_op(f"{NAMESPACE}::dit_forward",
-           mutates_args=("k_cache", "v_cache", "ck_cache", "cv_cache", "workspace", "evict_scratch", "kv_index"))
-def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], add_condition: Optional[Tensor],
-                k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor],
-                workspace: Tensor, evict_scratch: Optional[Tensor], init_cross: bool, cache_only: bool, sink: int, evict: int,
-                keep: int, write_start: int, attn_start: int, attn_end: int, start_frame: int,
-                kv_index: Optional[Tensor], global_end: int) -> Tuple[Tensor, Tensor]:
-    """One denoiser pass (CausalWanModel._forward_inference + flow -> x0, sf_dit_forward).  Writes the new K/V rows
-    into k_cache / v_cache (and, with init_cross, the text K/V into ck_cache / cv_cache); returns (flow, x0), or two
-    empty tensors with cache_only.  kv_index (optional, int64 [num_layers, 2]): every row <- (global_end, attn_end),
-    the cache dicts' index tensors when they are views of one buffer."""
-    m = _model(model)
+def _forward_args(m, model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], add_condition: Optional[Tensor],
+                  k_cache, v_cache, ck_cache, cv_cache, workspace: Tensor, evict_scratch: Optional[Tensor], init_cross: bool,
+                  cache_only: bool, sink: int, evict: int, keep: int, write_start: int, attn_start: int, attn_end: int,
+                  start_frame: int, kv_index: Optional[Tensor], global_end: int):
+    """Validate one pass's tensors and fill its sf_forward_args; returns (args, flow, x0) with empty outputs for cache_only."""
     _need_gpu(noisy, "noisy")
     _need_gpu(timestep, "timestep", None)
     if noisy.dim() != 5 or not noisy.is_contiguous() or timestep.dim() != 2 or not timestep.is_contiguous():
@@ -317,16 +312,67 @@ def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Opti
         if kv_index.dtype != torch.int64 or not kv_index.is_cuda or not kv_index.is_contiguous() or tuple(kv_index.shape) != (L, 2):
             raise ValueError(f"dit_forward: kv_index must be a contiguous CUDA int64 [{L}, 2] tensor")
         a.kv_index_out, a.global_end = kv_index.data_ptr(), global_end
-    fn, st = _lib.lib().sf_dit_forward, _stream(noisy)
+    return a, flow, x0
+
+
+def _timed_call(fn, *args) -> int:
+    """The C call, with its wall and CPU time booked to the calling thread (HOST_ENQUEUE)."""
     t0, c0 = time.perf_counter(), time.thread_time()
-    rc = fn(C.byref(m.cmodel), C.byref(a), st)
+    rc = fn(*args)
     dt, dc = time.perf_counter() - t0, time.thread_time() - c0
     rec = HOST_ENQUEUE.setdefault(threading.get_ident(), [0, 0.0, 0.0])
     rec[0] += 1
     rec[1] += dt
     rec[2] += dc
-    _lib.check(rc, "sf_dit_forward")
+    return rc
+
+
+@custom_op(f"{NAMESPACE}::dit_forward",
+           mutates_args=("k_cache", "v_cache", "ck_cache", "cv_cache", "workspace", "evict_scratch", "kv_index"))
+def dit_forward(model: int, noisy: Tensor, timestep: Tensor, prompt_embeds: Optional[Tensor], add_condition: Optional[Tensor],
+                k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor],
+                workspace: Tensor, evict_scratch: Optional[Tensor], init_cross: bool, cache_only: bool, sink: int, evict: int,
+                keep: int, write_start: int, attn_start: int, attn_end: int, start_frame: int,
+                kv_index: Optional[Tensor], global_end: int) -> Tuple[Tensor, Tensor]:
+    """One denoiser pass (CausalWanModel._forward_inference + flow -> x0, sf_dit_forward).  Writes the new K/V rows
+    into k_cache / v_cache (and, with init_cross, the text K/V into ck_cache / cv_cache); returns (flow, x0), or two
+    empty tensors with cache_only.  kv_index (optional, int64 [num_layers, 2]): every row <- (global_end, attn_end),
+    the cache dicts' index tensors when they are views of one buffer."""
+    m = _model(model)
+    a, flow, x0 = _forward_args(m, model, noisy, timestep, prompt_embeds, add_condition, k_cache, v_cache, ck_cache, cv_cache, workspace,
+                                evict_scratch, init_cross, cache_only, sink, evict, keep, write_start, attn_start, attn_end, start_frame,
+                                kv_index, global_end)
+    _lib.check(_timed_call(_lib.lib().sf_dit_forward, C.byref(m.cmodel), C.byref(a), _stream(noisy)), "sf_dit_forward")
     return flow, x0
+
+
+@custom_op(f"{NAMESPACE}::dit_forward_pair",
+           mutates_args=("k_cache", "v_cache", "ck_cache", "cv_cache", "workspace", "evict_scratch", "kv_index"))
+def dit_forward_pair(model: int, ctx_noisy: Tensor, ctx_timestep: Tensor, noisy: Tensor, timestep: Tensor,
+                     k_cache: List[Tensor], v_cache: List[Tensor], ck_cache: List[Tensor], cv_cache: List[Tensor],
+                     workspace: Tensor, evict_scratch: Optional[Tensor], ctx_plan: List[int], plan: List[int],
+                     kv_index: Optional[Tensor], global_end: int) -> Tuple[Tensor, Tensor]:
+    """The context pass of one chunk (cache_only) and the first denoising pass of the next in ONE call
+    (sf_dit_forward_pair): bit-identical to the two calls, twice the rows per GEMM.  `ctx_plan` / `plan` =
+    [sink, evict, keep, write_start, attn_start, attn_end, start_frame] of the two passes; workspace sized for 2 x batch.
+    Returns (flow, x0) of the denoising pass."""
+    m = _model(model)
+    if len(ctx_plan) != 7 or len(plan) != 7 or ctx_noisy.shape != noisy.shape or ctx_timestep.shape != timestep.shape:
+        raise ValueError("dit_forward_pair: two passes of one shape with 7 plan integers each expected")
+    a0, _, _ = _forward_args(m, model, ctx_noisy, ctx_timestep, None, None, k_cache, v_cache, ck_cache, cv_cache, workspace, evict_scratch,
+                             False, True, *ctx_plan, None, 0)
+    a1, flow, x0 = _forward_args(m, model, noisy, timestep, None, None, k_cache, v_cache, ck_cache, cv_cache, workspace, evict_scratch,
+                                 False, False, *plan, kv_index, global_end)
+    _lib.check(_timed_call(_lib.lib().sf_dit_forward_pair, C.byref(m.cmodel), C.byref(a0), C.byref(a1), _stream(noisy)), "sf_dit_forward_pair")
+    return flow, x0
+
+
+@dit_forward_pair.register_fake
+def _(model, ctx_noisy, ctx_timestep, noisy, timestep, k_cache, v_cache, ck_cache, cv_cache, workspace, evict_scratch, ctx_plan, plan,
+      kv_index, global_end):
+    B, F, _, H, W = noisy.shape
+    out_dim = _model(model).shape.out_dim
+    return noisy.new_empty((B, F, out_dim, H, W)), noisy.new_empty((B, F, out_dim, H, W))
 
 
 @dit_forward.register_fake
@@ -389,4 +435,4 @@ def _(model, ids, mask, buckets, workspace):
     return ids.new_empty((ids.shape[0], ids.shape[1], _model(model).shape.dim), dtype=torch.bfloat16)
 
 
-OPS = ("attention", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "vae_decode_frames", "t5_encode")
+OPS = ("attention", "gemm", "gemm_out", "lincomb", "lincomb_out", "add_noise", "dit_forward", "dit_forward_pair", "vae_decode_frames", "t5_encode")

@@ -179,6 +179,58 @@ class WanDiffusionWrapper(torch.nn.Module):
                 kv["local_end_index"].fill_(local_end)
         d0["_sf_mirror"] = (d0["global_end_index"], d0["local_end_index"], global_end, local_end)
 
+    # --- two passes in one call ------------------------------------------------------------------
+    def can_pair(self, conditional_dict: dict) -> bool:
+        """`forward_pair` covers the plain text-conditioned rollout (no pose tokens / image conditioning)."""
+        return conditional_dict.get("add_condition") is None and conditional_dict.get("clip_feature") is None \
+            and conditional_dict.get("y") is None
+
+    @torch.no_grad()
+    def forward_pair(self, context_input: Tensor, context_timestep: Tensor, noisy_image_or_video: Tensor, timestep: Tensor,
+                     conditional_dict: dict, kv_cache: List[dict], crossattn_cache: List[dict], context_start: int, current_start: int):
+        """Extension (no counterpart call in the reference, which runs these back to back, causal_inference.py:226-235 then
+        :190-205 of the next chunk): the context pass of one chunk -- `context_input` = its denoised latents at
+        `context_timestep`, cache positions from `context_start`, only the KV cache is updated -- and the FIRST denoising
+        pass of the next chunk (`noisy_image_or_video`, `timestep`, `current_start`) as one call.  Same results bit for
+        bit as `forward(..., cache_only=True)` followed by `forward(...)`; returns (flow_pred, pred_x0) of the second."""
+        mdl = self.model
+        shape = mdl.shape
+        xs = []
+        for x in (context_input, noisy_image_or_video):
+            assert x.dim() == 5 and x.shape[2] == shape.in_dim, "inputs must be [B, F, C, H, W] latents"
+            xs.append(x.to(device=mdl.device, dtype=torch.bfloat16).contiguous())
+        assert xs[0].shape == xs[1].shape, "forward_pair: both passes must have the same number of frames"
+        B, F, _, H, W = xs[1].shape
+        ts = []
+        for t in (context_timestep, timestep):
+            t = t.to(mdl.device)
+            if t.dim() == 1:
+                t = t.unsqueeze(1)
+            ts.append((t if t.dtype == torch.int64 else t.to(torch.float32)).contiguous())
+        assert ts[0].shape == ts[1].shape and ts[0].dtype == ts[1].dtype and ts[0].shape[0] == B, "forward_pair: timesteps must match in shape and dtype"
+        assert len(kv_cache) == mdl.num_layers and len(crossattn_cache) == mdl.num_layers
+        assert crossattn_cache[0]["is_init"], "forward_pair: the cross-attention cache is filled by the chunk's earlier passes"
+        fs = (H // 2) * (W // 2)
+        n_new = F * fs
+        cap = kv_cache[0]["k"].shape[1]
+        window = cap if mdl.local_attn_size == -1 else mdl.local_attn_size * fs
+        global_end, local_end = self._read_indices(kv_cache)
+        plan0 = plan_cache_update(local_end, global_end, context_start, n_new, cap, mdl.local_attn_size, mdl.sink_size * fs, window)
+        plan1 = plan_cache_update(plan0.local_end, plan0.global_end, current_start, n_new, cap, mdl.local_attn_size, mdl.sink_size * fs, window)
+        scratch = None
+        if plan0.evict > 0 or plan1.evict > 0:
+            need = B * max(plan0.keep, plan1.keep) * shape.dim * 2
+            if self._evict_scratch is None or self._evict_scratch.numel() < need:
+                self._evict_scratch = torch.empty(B * cap * shape.dim * 2, dtype=torch.uint8, device=mdl.device)
+            scratch = self._evict_scratch
+        index_buf = self._shared_index_buffer(kv_cache)
+        flow, x0 = mdl.forward_pair(xs[0], ts[0], xs[1], ts[1], [kv["k"] for kv in kv_cache], [kv["v"] for kv in kv_cache],
+                                    [c["k"] for c in crossattn_cache], [c["v"] for c in crossattn_cache], plan0, plan1,
+                                    context_start // fs, current_start // fs, scratch, kv_index=index_buf)
+        self._write_indices(kv_cache, plan1.global_end, plan1.local_end, done_by_kernel=index_buf is not None)
+        self._pace(mdl.device)
+        return flow, x0
+
     # --- the hot call --------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, noisy_image_or_video: Tensor, conditional_dict: dict, timestep: Tensor,

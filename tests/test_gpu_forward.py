@@ -415,6 +415,38 @@ def test_add_condition_identity_projection_on_dim_5120_models():
         small(x.to(DEV), {"prompt_embeds": pe2, "add_condition": cond.to(DEV)}, t.to(DEV), p2.kv_cache1, p2.crossattn_cache, 0)
 
 
+@pytest.mark.parametrize("nfpb,frames,las,sink,batch", [(2, 6, -1, 0, 1), (1, 7, 3, 1, 1), (3, 6, -1, 0, 2), (1, 5, 2, 0, 2)])
+def test_pairing_the_context_pass_with_the_next_chunks_first_pass_is_bit_identical(sd_reduced, nfpb, frames, las, sink, batch):
+    """`sf_dit_forward_pair`: a chunk's context pass and the next chunk's first denoising pass as ONE call (twice the rows per
+    GEMM) against the reference's order, one call per pass: the same latents, the same K / V in every layer's cache and the
+    same cache indices, bit for bit -- global cache, rolling window with eviction in the paired pass, batch 1 and 2."""
+    g = torch.Generator().manual_seed(91 + frames)
+    noise = torch.randn(batch, frames, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(batch, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    eps = [torch.randn(batch * nfpb, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(3 * (frames // nfpb))]
+    res = []
+    for paired in (True, False):
+        pipe = make_pipe(sd_reduced, nfpb, False, 5.0, las=las, sink=sink, pe=pe)
+        pipe.pair_context_with_next = paired
+        calls = {"pair": 0, "single": 0}
+        gen = pipe.generator
+        fwd, fwd_pair = gen.forward, gen.forward_pair
+        gen.forward = lambda *a, _f=fwd, **k: (calls.__setitem__("single", calls["single"] + 1), _f(*a, **k))[1]
+        gen.forward_pair = lambda *a, _f=fwd_pair, **k: (calls.__setitem__("pair", calls["pair"] + 1), _f(*a, **k))[1]
+        q = list(eps)
+        pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+        lat = pipe.inference(noise, ["p"] * batch, return_latents=True)[1].clone()
+        torch.cuda.synchronize()
+        n_chunks = frames // nfpb
+        assert calls["pair"] == (n_chunks - 1 if paired else 0) and calls["single"] + 2 * calls["pair"] == 5 * n_chunks
+        res.append((lat, [kv["k"].clone() for kv in pipe.kv_cache1], [kv["v"].clone() for kv in pipe.kv_cache1],
+                    int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[-1]["local_end_index"])))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and a[3:] == b[3:]
+    for ka, kb, va, vb in zip(a[1], b[1], a[2], b[2]):
+        assert torch.equal(ka, kb) and torch.equal(va, vb)
+
+
 def test_host_pacing_bounds_the_queue_and_changes_nothing(sd_reduced):
     """`WanDiffusionWrapper.max_inflight_forwards` (host-side pacing: the calling thread polls the oldest pass's event
     between sleeps instead of spinning for launch-queue room): never more than that many passes' events outstanding, and
@@ -437,7 +469,7 @@ def test_host_pacing_bounds_the_queue_and_changes_nothing(sd_reduced):
             seen.append(len(_gen._inflight))
         pipe.generator._pace = pace
         outs.append(pipe.inference(noise, ["p"], return_latents=True)[1].clone())
-        assert len(seen) == 10 and max(seen) <= max(limit, 0)      # 2 chunks x (4 + 1) passes
+        assert len(seen) == 9 and max(seen) <= max(limit, 0)       # 2 chunks x (4 + 1) passes, one context pass paired with the next chunk's first
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
