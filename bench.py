@@ -477,6 +477,9 @@ def parse_args(argv=None):
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: every rank uses cuda:0 (needs --dist-backend gloo: RCCL "
                          "refuses two ranks on one device); the figures of such a run are not a scaling measurement")
+    ap.add_argument("--no-pair", action="store_true",
+                    help="one generator call per pass, as the reference (default: a chunk's context pass runs in ONE call with the "
+                         "next chunk's first denoising pass -- same latents bit for bit, twice the rows per GEMM)")
     ap.add_argument("--max-inflight", type=int, default=None,
                     help="host pacing: passes a wrapper keeps enqueued before its thread sleeps (default: the wrapper's 2; 0 = unpaced)")
     return ap.parse_args(argv)
@@ -534,6 +537,8 @@ def main():
     window = a.local_attn_size if a.local_attn_size > 0 else 0
     enc = sfa.SyntheticTextEncoder(shape.text_len, shape.text_dim, device=dev)
     pool = sfa.RolloutPool(args, dev, gen, lambda: enc, sfa.IdentityVAE, streams=a.streams)
+    for pipe in pool.pipes:
+        pipe.pair_context_with_next = not a.no_pair
 
     # every rank must hold the same replica: a checksum of the device-resident weights, compared over RCCL
     grp.check_replicas(float(torch.stack([t.float().sum() for t in gen.model._keep[:64]]).sum().double().item()))
@@ -618,6 +623,7 @@ def main():
                                + f"{B} prompt(s) per rollout call, {a.streams} rollout call(s) in flight per GPU "
                                f"(one HIP stream each, shared weights), prompts sharded rank::N",
                    "forwards_per_step": (a.frames // nfpb) * (len(step_list) + 1), "tokens_per_chunk": nfpb * fs,
+                   "passes_paired": (not a.no_pair) and B * nfpb * fs <= pool.pipes[0].pair_max_rows,
                    "parallelism": f"prompt-sharded x{world}" + (" (REHEARSAL: all ranks on one GPU, gloo collectives)" if a.same_device and world > 1 else ""),
                    "streams_per_gpu": a.streams, "batch_per_rollout": B},
         "algorithmic_tflop_per_step": flops / 1e12,

@@ -428,6 +428,7 @@ def test_pairing_the_context_pass_with_the_next_chunks_first_pass_is_bit_identic
     for paired in (True, False):
         pipe = make_pipe(sd_reduced, nfpb, False, 5.0, las=las, sink=sink, pe=pe)
         pipe.pair_context_with_next = paired
+        assert batch * nfpb * FS <= pipe.pair_max_rows
         calls = {"pair": 0, "single": 0}
         gen = pipe.generator
         fwd, fwd_pair = gen.forward, gen.forward_pair
