@@ -159,6 +159,12 @@ def test_entry_points_reject_bad_arguments_without_touching_the_gpu():
     g.M, g.N, g.K = 4, 8, 100
     assert lib.sf_gemm_bf16(g, None) != 0 and b"K=100" in lib.sf_last_error()
     assert lib.sf_attention(None, None, None, None, 1, 1, 1, 1, 128, 128, 128, 128, 128, 128, None) != 0
+    # the two-pass call: null arguments, and two passes that do not name the same workspace
+    assert lib.sf_dit_forward_pair(None, None, None, None) != 0 and b"null" in lib.sf_last_error()
+    m, a0, a1 = sfa._lib.Model(), sfa._lib.ForwardArgs(), sfa._lib.ForwardArgs()
+    a0.workspace, a1.workspace = 16, 32
+    assert lib.sf_dit_forward_pair(m, a0, a1, None) != 0 and b"same workspace" in lib.sf_last_error()
+    assert lib.sf_probe_copy(None, None, 64, None) != 0 and lib.sf_probe_mfma(0, 0, 0, None, None, None, None) != 0
 
 
 def test_ops_refuse_cpu_tensors():
