@@ -199,10 +199,18 @@ def max_items(sbuf, masked, kb):
         it.append(("valu", f"v_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(sreg(qb, 15))}"))
     for qb in range(2):   # across the lane pair (l, l+32) that shares a query column
         it.append(("valu", f"v_mov_b32 {vr(TMP + qb)}, {vr(MX[qb])}"))
+    # hazard: a VGPR written by a VALU instruction needs two wait states before v_permlane32_swap reads it (hipcc puts
+    # `s_nop 1` between a v_mov and the swap); the swap's results need none.  With the two query blocks interleaved --
+    # mov0, mov1, s_nop 0, swap0, swap1, max0, max1 -- ONE s_nop would cover both; `--abl fewnops` drops the other three
+    # (bit-identical, and within 0.2 % in time at every Lk, round 3: these slots sit in the P.V phases, which are not the
+    # ones that bound the tile), so the stream keeps the conservative four.
+    old = "fewnops" not in ABL
     for qb in range(2):
-        it.append(("valu", f"s_nop 0\n\tv_permlane32_swap_b32 {vr(MX[qb])}, {vr(TMP + qb)}"))
+        pre = "s_nop 0\n\t" if (old or qb == 0) else ""
+        it.append(("valu", f"{pre}v_permlane32_swap_b32 {vr(MX[qb])}, {vr(TMP + qb)}"))
     for qb in range(2):
-        it.append(("valu", f"s_nop 0\n\tv_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(TMP + qb)}"))
+        pre = "s_nop 0\n\t" if old else ""
+        it.append(("valu", f"{pre}v_max_f32 {vr(MX[qb])}, {vr(MX[qb])}, {vr(TMP + qb)}"))
     return it
 
 
