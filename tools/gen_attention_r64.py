@@ -46,6 +46,8 @@ if "--abl" in sys.argv:
 
 ALIGN = int(sys.argv[sys.argv.index("--align") + 1]) if "--align" in sys.argv else 6    # log2 bytes; 0 = none
 PAD = int(sys.argv[sys.argv.index("--pad") + 1]) if "--pad" in sys.argv else 0          # extra 4-byte s_nops behind it
+# how many of a wave's LDS-DMA requests may still be in flight behind the wait at the top of a (steady-state) tile
+TOP_VMCNT = int(sys.argv[sys.argv.index("--top-vmcnt") + 1]) if "--top-vmcnt" in sys.argv else 4
 # where a tile's eight LDS-DMA requests are issued: K pieces placed in phases A / B, V pieces in C / D ("n_in_A,n_in_C":
 # how many of the four go to the FIRST phase of each pair; 0,0 = all four K requests in B and all four V requests in D)
 DMA_SPLIT = [int(x) for x in (sys.argv[sys.argv.index("--dma-split") + 1] if "--dma-split" in sys.argv else "0,0").split(",")]
@@ -400,7 +402,7 @@ def body(kind):
     # MX holds the row maxima of unit 0 (taken in the previous phase D / prologue)
     lds.reset(8)
     phase.tags = {("k", s): s for s in range(8)}
-    e("s_waitcnt vmcnt(4)" if kind == "normal" else "s_waitcnt vmcnt(0)")
+    e(f"s_waitcnt vmcnt({TOP_VMCNT})" if kind == "normal" else "s_waitcnt vmcnt(0)")
     if "nobarrier" not in ABL:
         e("s_barrier")
     dma_k = dma_v = []
