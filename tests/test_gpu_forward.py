@@ -448,6 +448,29 @@ def test_pairing_the_context_pass_with_the_next_chunks_first_pass_is_bit_identic
         assert torch.equal(ka, kb) and torch.equal(va, vb)
 
 
+def test_streaming_with_paired_passes_yields_the_same_chunks(sd_reduced):
+    """`stream()` (chunk-at-a-time, last context pass skipped as demo.py does) with the context pass of chunk k paired with
+    chunk k + 1's first pass: the same latents per chunk as with one call per pass, and as the batch `inference()`."""
+    g = torch.Generator().manual_seed(97)
+    noise = torch.randn(1, 6, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16).to(DEV)
+    pe = torch.randn(1, 512, sfa.WAN_REDUCED.text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    eps = [torch.randn(2, 16, LAT_H, LAT_W, generator=g).to(torch.bfloat16) for _ in range(9)]
+    outs = {}
+    for paired in (True, False):
+        pipe = make_pipe(sd_reduced, 2, False, 5.0, pe=pe)
+        pipe.pair_context_with_next = paired
+        q = list(eps)
+        pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+        outs[paired] = [x.clone() for _, x, _ in pipe.stream(noise, ["p"])]
+        assert not q                                            # every re-noise tensor was consumed, in order
+    assert len(outs[True]) == 3 and all(torch.equal(a, b) for a, b in zip(outs[True], outs[False]))
+    pipe = make_pipe(sd_reduced, 2, False, 5.0, pe=pe)
+    q = list(eps)
+    pipe.noise_source = lambda t: q.pop(0).reshape(t.shape)
+    lat = pipe.inference(noise, ["p"], return_latents=True)[1]
+    assert torch.equal(torch.cat(outs[True], dim=1), lat)
+
+
 def test_host_pacing_bounds_the_queue_and_changes_nothing(sd_reduced):
     """`WanDiffusionWrapper.max_inflight_forwards` (host-side pacing: the calling thread polls the oldest pass's event
     between sleeps instead of spinning for launch-queue room): never more than that many passes' events outstanding, and
