@@ -666,6 +666,8 @@ def main():
         out["roofline"] = att
         out["gemm"] = gemm
         out["mfma_frac_end_to_end_of_measured_peak"] = out["achieved_tflops_per_gpu"] / att["measured_peak"]
+        out["hbm_measured_peak"] = {"value": peaks["hbm_copy_GBps"], "unit": "GB/s (read + write)", "kernel": "sf_probe_copy, 1 GiB, 4 x 16 B per lane in flight",
+                                    "datasheet": 8000.0}
         out["hbm_bound"] = hbm_bound_leg(shape, dev, nfpb, fs, batch=B, peaks=peaks)
         if B != 1:
             out["hbm_bound"]["at_batch_1"] = hbm_bound_leg(shape, dev, nfpb, fs, batch=1, peaks=peaks)
